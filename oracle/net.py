@@ -1,0 +1,105 @@
+"""Network oracle: torch-CPU fp32 restatement of the L3C forward (TEST INFRASTRUCTURE ONLY, see oracle/__init__.py).
+
+A *functional* restatement -- no nn.Module tree; it walks a reference state-dict (key schema: SURVEY.md section 5 /
+Appendix A) with F.conv2d.  Restates, for the L3C configuration (configs/ms/cr.cf: EDSRLikeEnc / EDSRDec, enc.feed_F,
+dec.skip, non-recursive):
+  conv                <- pytorch_ext.default_conv :57-61 (padding = k//2, or = dilation when dilated)
+  encoder             <- modules/net.py EDSRLikeEnc.forward :136-148, edsr.ResBlock :83-86
+  quantise            <- modules/quantizer.py Quantizer.forward :62-90 (eval: hard symbols, first-min of torch.min)
+  decoder             <- modules/net.py EDSRDec.forward :173-184, edsr.Upsampler :92-119 (conv 64->256 + PixelShuffle(2))
+  prob_clf            <- modules/prob_clf.py StackedAtrousConvs.forward :71-74
+  forward / get_P     <- modules/multiscale_network.py :226-246, :260-306, :308-322 (eval mode: decoders are fed bn_q)
+The RGB baselines (BicubicSubsampling) are not restated here ("next").
+"""
+from collections import namedtuple
+
+import torch
+import torch.nn.functional as F
+
+Hyper = namedtuple('Hyper', ['num_scales', 'Cf', 'C', 'L', 'K', 'enc_blocks', 'dec_blocks', 'levels_range'])
+L3C_HYPER = Hyper(num_scales=3, Cf=64, C=5, L=25, K=10, enc_blocks=8, dec_blocks=8, levels_range=(-1, 1))
+
+EncOut = namedtuple('EncOut', ['bn', 'bn_q', 'S', 'F'])
+Out = namedtuple('Out', ['S', 'L', 'bn', 'P', 'F_enc', 'F_dec'])
+
+
+def conv(x, sd, key, stride=1, rate=1):
+    w, b = sd[key + '.weight'], sd[key + '.bias']
+    k = w.shape[-1]
+    return F.conv2d(x, w, b, stride=stride, dilation=rate, padding=(k // 2 if rate == 1 else rate))
+
+
+def _body(x, sd, prefix, num_blocks):
+    for i in range(num_blocks):
+        r = conv(x, sd, '{}.{}.body.0'.format(prefix, i))
+        r = F.relu(r)
+        r = conv(r, sd, '{}.{}.body.2'.format(prefix, i))
+        x = r + x
+    return conv(x, sd, '{}.{}'.format(prefix, num_blocks))
+
+
+def quantise(x, levels):
+    N, C, H, W = x.shape
+    d = torch.pow(x.reshape(N, C, H * W, 1) - levels, 2)
+    _, sym = torch.min(d, dim=-1)
+    sym = sym.view(N, C, H, W)
+    return levels[sym], sym
+
+
+def encoder(x, sd, s, hp):
+    p = 'nets.{}.enc'.format(s)
+    x = conv(x, sd, p + '.down', stride=2)
+    x = _body(x, sd, p + '.body', hp.enc_blocks) + x
+    feat = x
+    bn = conv(x, sd, p + '.to_q.0')
+    bn_q, sym = quantise(bn, sd[p + '.levels'])
+    return EncOut(bn, bn_q, sym, feat)
+
+
+def decoder(bn_q, fuse, sd, s, hp):
+    p = 'nets.{}.dec'.format(s)
+    x = conv(bn_q, sd, p + '.head')
+    if fuse is not None:
+        x = x + fuse
+    x = _body(x, sd, p + '.body', hp.dec_blocks) + x
+    x = conv(x, sd, p + '.tail.0')
+    return F.pixel_shuffle(x, 2)
+
+
+def prob_clf(feat, sd, s):
+    p = 'prob_clfs.{}.atrous'.format(s)
+    x = torch.cat([conv(feat, sd, '{}.atrous.{}'.format(p, i), rate=r) for i, r in enumerate((1, 2, 4))], dim=1)
+    return conv(x, sd, p + '.lin')
+
+
+def head(x, sd, s):
+    if s == 0:
+        x = conv(x, sd, 'heads.0.head.0')
+        return conv(x, sd, 'heads.0.head.1.head')
+    return conv(x, sd, 'heads.{}.head'.format(s))
+
+
+def forward(img, sd, hp=L3C_HYPER):
+    """img: (N,3,H,W) float 0..255 -> Out (lists fine->coarse as in multiscale_network.Out)."""
+    S, Ls, bn = [img.round().long()], [256], [None]
+    x = conv(img, sd, 'sub_rgb_mean')
+    encs = []
+    for s in range(hp.num_scales):
+        e = encoder(head(x, sd, s), sd, s, hp)
+        encs.append(e)
+        x = e.F
+    decs = [None] * hp.num_scales
+    for s in reversed(range(hp.num_scales)):
+        fuse = None if s == hp.num_scales - 1 else decs[s + 1]
+        decs[s] = decoder(encs[s].bn_q, fuse, sd, s, hp)
+    P = [prob_clf(decs[s], sd, s) for s in range(hp.num_scales)]
+    for e in encs:
+        S.append(e.S)
+        Ls.append(hp.L)
+        bn.append(e.bn_q)
+    return Out(S, Ls, bn, P, [e.F for e in encs], decs)
+
+
+def get_P(scale, bn_q, dec_F_prev, sd, hp=L3C_HYPER):
+    f = decoder(bn_q, dec_F_prev, sd, scale, hp)
+    return prob_clf(f, sd, scale), f

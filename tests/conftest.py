@@ -1,0 +1,39 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'reference: needs /root/reference (build container only)')
+
+
+def pytest_collection_modifyitems(config, items):
+    have_ref = os.path.isdir('/root/reference/src')
+    skip_ref = pytest.mark.skip(reason='/root/reference not present (GPU box)')
+    for item in items:
+        if 'reference' in item.keywords and not have_ref:
+            item.add_marker(skip_ref)
+
+
+@pytest.fixture(scope='session')
+def golden():
+    def load(name):
+        return np.load(os.path.join(GOLDEN, name))
+    return load
+
+
+@pytest.fixture(scope='session')
+def synthetic_l3c():
+    """(config_ms, state_dict) of the seeded synthetic L3C checkpoint used by tests/golden/make_golden.py."""
+    import l3c_pytorch_amd  # noqa: F401
+    from l3c_pytorch_amd.helpers import config_parser, synthetic
+    cfg = config_parser.parse_builtin('ms', 'cr')
+    return cfg, synthetic.make_state_dict(cfg, 0)
