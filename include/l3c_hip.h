@@ -1,0 +1,198 @@
+/*
+ * l3c_hip.h -- C ABI of libl3c_hip.so: the MI355X-native (gfx950) L3C inference path.
+ *
+ * This is the drop-in boundary.  The reference's native FFI for this path is the pybind11 torch
+ * extension `torchac_backend_gpu` / `torchac_backend_cpu` (src/torchac/torchac_backend/torchac.cpp:433-443) plus the cuDNN
+ * convolutions it reaches through torch.nn; everything below replaces one of those call sites with a HIP kernel behind
+ * plain pointers and sizes -- no torch types, no hidden allocation, no hidden synchronisation.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is enqueued asynchronously;
+ *   - every function returns L3C_OK (0) or a negative status; l3c_last_error() returns a thread-local message;
+ *   - buffers are caller-owned; sizes are element counts unless the name says `_bytes`;
+ *   - activations are fp32 "pixel-major" (NHWC): element (b, y, x, c) lives at ((b*H + y)*W + x)*cstride + coff + c,
+ *     where `cstride` is the number of channels per pixel in memory (lets a conv write a channel slice of a wider tensor);
+ *   - symbols are int16, planar (b, c, y*W + x) like the reference hands them to its coder (bitcoding/coders.py:46-51).
+ */
+#ifndef L3C_HIP_H_
+#define L3C_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define L3C_OK 0
+#define L3C_ERR_INVALID_ARG (-1)
+#define L3C_ERR_HIP (-2)
+#define L3C_ERR_UNSUPPORTED (-3)
+
+#define L3C_ABI_VERSION 1
+
+typedef void *l3c_stream_t;
+
+/* ---- library ------------------------------------------------------------------------------------------------------ */
+
+int l3c_abi_version(void);
+/* Thread-local description of the last failing call ("" if none). */
+const char *l3c_last_error(void);
+/* Name / CU count / gcnArchName of the current HIP device; fails when no GPU is visible (there is no CPU fallback). */
+int l3c_device_info(char *name_host, int name_cap, int *num_cu_host, char *arch_host, int arch_cap);
+
+/* ---- arithmetic coder (replaces torchac.cpp) ---------------------------------------------------------------------- */
+
+/*
+ * Packed coding interval of one symbol: bits 0..15 = c_low, bits 16..31 = c_high - 1 (c_high in 1..65536).
+ * Interval streams are stored in blocks of 64 symbols: word(stream s, symbol t) = iv[((t/64)*n_streams + s)*64 + t%64],
+ * so the kernel that writes them and the lane that codes stream s both touch contiguous 256-byte runs.
+ * l3c_interval_words(n_streams, n_sym) gives the buffer size in uint32 words.
+ */
+int64_t l3c_interval_words(int64_t n_streams, int64_t n_sym);
+
+/*
+ * Intervals from an explicit CDF table (the reference's encode_cdf path, torchac.cpp:263-269 -> encode() :174-182:
+ * c_low = cdf[i*Lp + s], c_high = s == Lp-2 ? 0x10000 : cdf[i*Lp + s + 1]).
+ *   cdf        uint16 [n_streams][n_sym][Lp] when row_stride == Lp; row_stride == 0 broadcasts ONE row of Lp entries
+ *              to every symbol of every stream (uniform prior of the coarsest scale, bitcoding.py:297-323)
+ *   sym        int16 [n_streams][n_sym]
+ */
+int l3c_ac_intervals_from_table(const uint16_t *cdf, int64_t row_stride, int Lp, const int16_t *sym,
+                                int64_t n_streams, int64_t n_sym, uint32_t *intervals, l3c_stream_t stream);
+
+/*
+ * Range-encode n_streams independent symbol streams of equal length, one stream per lane (64 streams per wavefront).
+ * Bit-exact restatement of encode() (torchac.cpp:152-227): 32-bit low/high, 16-bit precision, pending-bit carry
+ * handling, final flush `pending+1` bits, zero padding to a byte boundary, MSB-first.
+ *   out        uint8 [n_streams][out_stride_bytes]; out_stride_bytes % 4 == 0 and >= l3c_ac_max_bytes(n_sym)
+ *   out_nbytes uint32 [n_streams]   number of bytes produced per stream
+ */
+int64_t l3c_ac_max_bytes(int64_t n_sym);
+int l3c_ac_encode(const uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t *out,
+                  int64_t out_stride_bytes, uint32_t *out_nbytes, l3c_stream_t stream);
+
+/*
+ * Range-decode n_streams streams, one wavefront per stream (the 64 lanes hold the CDF row of the current symbol and
+ * rank the decoder's `count` against it).  Bit-exact restatement of decode() (torchac.cpp:299-381) including the
+ * reference binary search (binsearch :276-296) and the skipped state update of the last symbol.
+ *   cdf         uint16 rows as above (row_stride == Lp or 0), Lp <= 257
+ *   in          uint8, stream s occupies in[in_offsets[s] .. in_offsets[s] + in_nbytes[s]); bits past the end read 0
+ *   monotone    1: every row is known to be strictly increasing over [0, Lp-2] (rank == reference binsearch; fast path)
+ *               0: use the literal binary search of the reference for every symbol
+ *   sym_out     int16 [n_streams][n_sym]
+ */
+int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t *in, const int64_t *in_offsets,
+                  const uint32_t *in_nbytes, int64_t n_streams, int64_t n_sym, int monotone, int16_t *sym_out,
+                  l3c_stream_t stream);
+
+/* flag_out[0] |= 1 when some row of the table is not strictly increasing over entries [0, Lp-2]. */
+int l3c_cdf_check_monotone(const uint16_t *cdf, int64_t n_rows, int Lp, int32_t *flag_out, l3c_stream_t stream);
+
+/* ---- logistic-mixture head (replaces torchac_kernel.cu + criterion/logistic_mixture.py on the coding path) --------- */
+
+/*
+ * Per-channel mixture parameters, the reference's CDFOut (logistic_mixture.py:134-141, :248-275):
+ *   P      fp32 pixel-major [B][HW][Kp], Kp = (rgb ? 4 : 3) * C * K, channel index p*(C*K) + c*K + k
+ *   sym    int16 planar [B][C][HW]; only read for rgb && c > 0 (lambda coupling with the ACTUAL values of the previous
+ *          channels: mu_G += sigmoid(lam_0) x_R, mu_B += sigmoid(lam_1) x_R + sigmoid(lam_2) x_G)
+ *   out    pi (softmax over K), mu, log_sigma (clamped at -7): fp32 planar [B][K][HW] each -- the 1KHW layout of CDFOut
+ */
+int l3c_dmll_channel_params(const float *P, const int16_t *sym, int64_t B, int64_t HW, int C, int K, int rgb, int c,
+                            float *pi, float *mu, float *log_sigma, l3c_stream_t stream);
+
+/*
+ * uint16 CDF table of a logistic mixture -- calculate_cdf_kernel (torchac_kernel.cu:26-76) / _get_uint16_cdf
+ * (torchac.py:174-213):  cdf[n][l] = uint16(lrintf(sum_k pi[k][n] * sigmoid((t[l] - mu[k][n]) * exp(-ls[k][n]))
+ *                                                  * (65536 - (Lp - 1))) + l)
+ *   targets fp32 [Lp]; pi, mu, log_sigma fp32 planar [n_img][K][HW]; cdf uint16 [n_img][HW][Lp]
+ *   not_monotone (may be NULL) int32, |= 1 if a row is not strictly increasing over [0, Lp-2]
+ */
+int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu, const float *log_sigma,
+                          int64_t n_img, int64_t HW, int K, int Lp, uint16_t *cdf, int32_t *not_monotone,
+                          l3c_stream_t stream);
+
+/*
+ * Fused encoder head: straight from the network output P and the symbols to the packed coding intervals of every
+ * channel of one scale -- only the two table entries the encoder reads (torchac.cpp:180-181) are evaluated, with the
+ * same per-entry arithmetic as l3c_cdf_table_mixture, so the result is bit-identical to building the table first.
+ *   stream index = b*C + c, n_streams = B*C, n_sym = HW; intervals sized by l3c_interval_words(B*C, HW)
+ */
+int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C,
+                              int K, int rgb, int Lp, uint32_t *intervals, l3c_stream_t stream);
+
+/*
+ * Negative log-likelihood map of DiscretizedMixLogisticLoss.forward (logistic_mixture.py:146-207):
+ *   x      fp32 planar [B][C][HW] targets (pixel values for rgb, bottleneck values for z scales)
+ *   nll    fp32 planar [B][C][HW], nats
+ */
+int l3c_dmll_nll(const float *P, const float *x, int64_t B, int64_t HW, int C, int K, int rgb, float x_min,
+                 float x_max, int L, float *nll, l3c_stream_t stream);
+
+/* ---- convolution stack (replaces the cuDNN convs behind modules/{net,edsr,head,prob_clf}.py) ---------------------- */
+
+/*
+ * Weight pre-packing for l3c_conv_mfma: w_oihw fp32 [Cout][Cin][KS][KS] (the checkpoint layout) -> MFMA fragment
+ * order.  l3c_conv_packed_words gives the size of `packed` in floats.  Cin % 16 == 0.
+ */
+int64_t l3c_conv_packed_words(int Cout, int Cin, int KS);
+int l3c_conv_pack_weights(const float *w_oihw, int Cout, int Cin, int KS, float *packed, l3c_stream_t stream);
+
+#define L3C_EPI_RELU 1         /* max(0, .) after the bias */
+#define L3C_EPI_RESIDUAL 2     /* += residual[pixel][cout] after bias (and relu) */
+#define L3C_EPI_PIXEL_SHUFFLE 4 /* out[(2y+i, 2x+j)][n>>2] = conv[(y,x)][n], i = (n>>1)&1, j = n&1 (nn.PixelShuffle(2)) */
+
+typedef struct {
+    const float *in;       /* [B][Hin][Win][in_cstride], channels in_coff .. in_coff+Cin */
+    int in_cstride, in_coff;
+    const float *packed_w; /* from l3c_conv_pack_weights */
+    const float *bias;     /* [Cout] */
+    const float *residual; /* [B][Hout][Wout][res_cstride] (+res_coff), or NULL */
+    int res_cstride, res_coff;
+    float *out;            /* [B][Hout][Wout][out_cstride] (+out_coff); with PIXEL_SHUFFLE: [B][2Hout][2Wout][..] */
+    int out_cstride, out_coff;
+    int B, Hin, Win, Cin, Cout;
+    int KS;                /* 1, 3 or 5 */
+    int stride;            /* 1, or 2 (KS == 5 only) */
+    int dilation;          /* 1, 2 or 4 (KS == 3 only); padding is KS/2 when dilation == 1 else dilation */
+    int epilogue;          /* L3C_EPI_* flags */
+} l3c_conv_desc;
+
+/* fp32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32; Cin % 16 == 0 (64 or 192 on this path). */
+int l3c_conv_mfma(const l3c_conv_desc *desc_host, l3c_stream_t stream);
+/* Same contract on plain VALU FMAs with unpacked OIHW weights (packed_w = w_oihw): a device-side cross-check. */
+int l3c_conv_direct(const l3c_conv_desc *desc_host, l3c_stream_t stream);
+
+/*
+ * RGB head: img planar fp32 [B][3][H][W] (0..255) -> sub_rgb_mean (1x1, 3->3) -> MeanShift(1/128) (1x1, 3->3) ->
+ * conv 3x3 3->Cf, zero padding applied to the mean-shifted image.  (multiscale_network.py:241, head.py:26-41)
+ *   w1,b1  sub_rgb_mean [3][3],[3];  w2,b2 heads.0.head.0 [3][3],[3];  w3 [Cf][3][3][3], b3 [Cf];  out pixel-major
+ * shifted_out (may be NULL): planar [B][3][H][W], the input of the 3x3 conv, for stage-wise parity tests.
+ */
+int l3c_rgb_head(const float *img, const float *w1, const float *b1, const float *w2, const float *b2,
+                 const float *w3, const float *b3, int B, int H, int W, int Cf, float *out, float *shifted_out,
+                 l3c_stream_t stream);
+
+/*
+ * Encoder output: 1x1 conv Cf -> C (`to_q`, net.py:113-121) fused with the hard quantiser (quantizer.py:72-87:
+ * symbols = argmin_l (x - levels_l)^2, first minimum wins; x_hard = levels[symbols]).
+ *   feat pixel-major [B][HW][Cf]; w [C][Cf], b [C], levels [L]
+ *   sym int16 planar [B][C][HW]; bn_q fp32 planar [B][C][HW]; bn (may be NULL) pre-quantisation values, planar
+ */
+int l3c_to_q_quantize(const float *feat, const float *w, const float *b, const float *levels, int64_t B, int64_t HW,
+                      int Cf, int C, int L, int16_t *sym, float *bn_q, float *bn, l3c_stream_t stream);
+
+/*
+ * Decoder input: 1x1 conv C -> Cf on the quantised bottleneck (+ the coarser decoder's features), net.py:178-180.
+ *   bn_q planar [B][C][HW]; w [Cf][C], b [Cf]; fuse pixel-major [B][HW][Cf] or NULL; out pixel-major [B][HW][Cf]
+ */
+int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float *fuse, int64_t B, int64_t HW, int C,
+                 int Cf, float *out, l3c_stream_t stream);
+
+/* symbols -> bottleneck values, to_bn (quantizer.py:44-47): float(S) * bin + x_min, two separately rounded fp32 ops. */
+int l3c_sym_to_bn(const int16_t *sym, int64_t n, float bin_width, float x_min, float *bn, l3c_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* L3C_HIP_H_ */

@@ -1,0 +1,115 @@
+"""ctypes binding of the C ABI in include/l3c_hip.h (libl3c_hip.so, built by csrc/build.py).
+
+This is the reference-side binding a maintainer would add in place of `import torchac_backend_gpu`
+(src/torchac/torchac.py:36-48): raw device pointers (`tensor.data_ptr()`), sizes, and the current HIP stream.
+There is no CPU implementation behind it: a missing library or a CPU tensor raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libl3c_hip.so')
+
+c_i64, c_int, c_vp, c_f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
+
+
+class L3CError(RuntimeError):
+    pass
+
+
+class ConvDesc(ctypes.Structure):
+    """l3c_conv_desc (include/l3c_hip.h)."""
+    _fields_ = [('inp', c_vp), ('in_cstride', c_int), ('in_coff', c_int),
+                ('packed_w', c_vp), ('bias', c_vp),
+                ('residual', c_vp), ('res_cstride', c_int), ('res_coff', c_int),
+                ('out', c_vp), ('out_cstride', c_int), ('out_coff', c_int),
+                ('B', c_int), ('Hin', c_int), ('Win', c_int), ('Cin', c_int), ('Cout', c_int),
+                ('KS', c_int), ('stride', c_int), ('dilation', c_int), ('epilogue', c_int)]
+
+
+EPI_RELU, EPI_RESIDUAL, EPI_PIXEL_SHUFFLE = 1, 2, 4
+
+# name -> (restype, argtypes); must list every symbol include/l3c_hip.h declares (tests/test_abi.py checks)
+PROTOTYPES = {
+    'l3c_abi_version': (c_int, []),
+    'l3c_last_error': (ctypes.c_char_p, []),
+    'l3c_device_info': (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'l3c_interval_words': (c_i64, [c_i64, c_i64]),
+    'l3c_ac_intervals_from_table': (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'l3c_ac_max_bytes': (c_i64, [c_i64]),
+    'l3c_ac_encode': (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
+    'l3c_cdf_check_monotone': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
+    'l3c_dmll_channel_params': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'l3c_cdf_table_mixture': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
+    'l3c_dmll_encode_intervals': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'l3c_dmll_nll': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp]),
+    'l3c_conv_packed_words': (c_i64, [c_int, c_int, c_int]),
+    'l3c_conv_pack_weights': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
+    'l3c_conv_mfma': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
+    'l3c_conv_direct': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
+    'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'l3c_to_q_quantize': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'l3c_dec_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
+    'l3c_sym_to_bn': (c_int, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """The shared library, with prototypes installed.  Raises L3CError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise L3CError('libl3c_hip.so not found at {} -- build it with `python l3c-pytorch_amd/csrc/build.py` '
+                           '(or __graft_entry__.build()); there is no CPU fallback.'.format(LIB_PATH))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        if lib.l3c_abi_version() != 1:
+            raise L3CError('ABI version mismatch: library {} != binding 1'.format(lib.l3c_abi_version()))
+        _lib = lib
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise L3CError('libl3c_hip: {} (status {})'.format(load().l3c_last_error().decode(), rc))
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args))
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise L3CError('no HIP device visible: the l3c-pytorch_amd compute path runs on the GPU only (no CPU fallback)')
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise L3CError('expected a GPU tensor, got {} -- there is no CPU fallback'.format(t.device))
+    if not t.is_contiguous():
+        raise L3CError('expected a contiguous tensor')
+    if dtype is not None and t.dtype != dtype:
+        raise L3CError('expected dtype {}, got {}'.format(dtype, t.dtype))
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info():
+    name = ctypes.create_string_buffer(256)
+    arch = ctypes.create_string_buffer(256)
+    ncu = c_int(0)
+    call('l3c_device_info', name, 256, ctypes.byref(ncu), arch, 256)
+    return name.value.decode(), ncu.value, arch.value.decode()

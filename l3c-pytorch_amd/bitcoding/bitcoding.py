@@ -1,0 +1,280 @@
+"""Bitcoding -- `.l3c` container encode / decode with the whole data path on the GPU.
+
+Same surface as the reference's bitcoding/bitcoding.py (`Bitcoding(blueprint, times, compare_with_theory)`,
+`encode(img, pout) -> bpsp` :50-123, `decode(pin) -> 1CHW long` :125-161) and the same byte format (:326-375):
+
+    u16 x4  padding (left, right, top, bottom)
+    for scale = coarsest .. 0:   u8 C, u16 H, u16 W;  for each channel: u32 nbytes, payload;  magic 46 E2 84 92
+
+What changed is WHERE the work happens.  The reference loops over scales and channels in Python, builds one CDF table per
+channel, and range-codes it on one CPU thread (coders.py:38-66 -> torchac.cpp).  Here a batch of B equally sized images
+is pushed through
+    encoder:  net forward  ->  per scale ONE fused kernel P,symbols -> coding intervals of all B*C streams
+              ->  ONE range-coder launch per scale (a stream per lane)            -> bytes + lengths in HBM
+    decoder:  per scale get_P -> parameters -> uint16 tables -> ONE range-decoder launch (a stream per wavefront);
+              only the RGB scale is serial in its channels (R -> G -> B, the lambda coupling of logistic_mixture.py:262-272)
+and only finished byte strings cross PCIe.  `encode_batch` / `decode_batch` are the native entry points; `encode` /
+`decode` are the reference's one-image file API on top of them (auto-crop parts included).
+"""
+import os
+import struct
+
+import numpy as np
+import torch
+
+from .. import auto_crop, ops
+from ..helpers import pad
+from . import part_suffix_helper
+
+_MAGIC_VALUE_SEP = b'\x46\xE2\x84\x92'
+
+
+class _NullTimes(object):
+    """Stand-in for the reference's StackTimeLogger when no timing is requested."""
+
+    class _Ctx(object):
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+
+    def run(self, *a, **kw):
+        return self._Ctx()
+
+    prefix_scope = combine = run
+
+
+def uniform_cdf_row(L):
+    """The coarsest scale's table: round(cumsum(1/L) * 2^16) with a leading 0, as int16 (bitcoding.py:297-323).
+    Same fp32 torch ops as the reference so the row is bit-identical (L=25: 0, 2621, 5243, ...)."""
+    histo = torch.ones(L, dtype=torch.float32) / L
+    cdf = torch.cumsum(torch.ones(1, L) * histo, -1).mul_(2 ** 16).round()
+    cdf = torch.cat((torch.zeros(1, 1), cdf), dim=-1)
+    return cdf.to(torch.int16).reshape(-1)
+
+
+class EncodedBatch(object):
+    """Device-resident result of `Bitcoding.encode_batch`: per scale (coarse -> fine) the coder output of its B*C streams.
+    Nothing has been synchronised or copied to the host until `payloads()` / `to_bytes()` is called."""
+
+    def __init__(self, B, padded_shape):
+        self.B = B
+        self.padded_shape = padded_shape     # (H, W) of the padded images
+        self.scales = []                     # (C, H, W, out uint8 (B*C, stride), nbytes int32 (B*C,))
+
+    def total_payload_bytes(self):
+        """int64 device tensor (B,): entropy-coded bytes per image (no host sync)."""
+        tot = None
+        for C, H, W, out, nbytes in self.scales:
+            t = nbytes.to(torch.int64).reshape(self.B, C).sum(dim=1)
+            tot = t if tot is None else tot + t
+        return tot
+
+    def file_sizes(self):
+        """(B,) file size in bytes incl. the fixed framing: 8 + sum_scales (5 + 4*C + 4) + payload."""
+        overhead = 8 + sum(5 + 4 * C + 4 for C, _, _, _, _ in self.scales)
+        return self.total_payload_bytes() + overhead
+
+    def payloads(self):
+        """list over scales (coarse -> fine) of [B][C] bytes objects (one D2H copy per scale)."""
+        res = []
+        for C, H, W, out, nbytes in self.scales:
+            n = nbytes.cpu().numpy()
+            host = out[:, :int(n.max())].cpu().numpy()
+            res.append([[host[b * C + c, :n[b * C + c]].tobytes() for c in range(C)] for b in range(self.B)])
+        return res
+
+    def to_bytes(self, padding_tuples=None):
+        """-> list of B `.l3c` byte strings."""
+        pl = self.payloads()
+        files = []
+        for b in range(self.B):
+            pt = padding_tuples[b] if padding_tuples else (0, 0, 0, 0)
+            chunks = [struct.pack('<4H', *pt)]
+            for (C, H, W, _, _), scale_payloads in zip(self.scales, pl):
+                chunks.append(struct.pack('<BHH', C, H, W))
+                for p in scale_payloads[b]:
+                    chunks += [struct.pack('<I', len(p)), p]
+                chunks.append(_MAGIC_VALUE_SEP)
+            files.append(b''.join(chunks))
+        return files
+
+
+class Bitcoding(object):
+    def __init__(self, blueprint, times=None, compare_with_theory=False):
+        self.blueprint = blueprint
+        self.compare_with_theory = compare_with_theory
+        self.times = times if times is not None else _NullTimes()
+        self._const = {}
+
+    # ---- constants --------------------------------------------------------------------------------------------------
+
+    def _targets(self, dmll):
+        key = ('t', dmll.x_min, dmll.x_max, dmll.L)
+        if key not in self._const:
+            self._const[key] = dmll.coding_targets('cuda')
+        return self._const[key]
+
+    def _uniform_row(self, L):
+        key = ('u', L)
+        if key not in self._const:
+            self._const[key] = uniform_cdf_row(L).cuda()
+        return self._const[key]
+
+    def iter_scale_dmll(self):
+        """coarsest -> finest: (scale, dmll, uniform)   (reference :163-169)"""
+        net, losses = self.blueprint.net, self.blueprint.losses
+        for scale in reversed(range(net.scales + 1)):
+            yield (scale, losses.loss_dmol_rgb if scale == 0 else losses.loss_dmol_n, scale == net.scales)
+
+    # ---- native batched API -----------------------------------------------------------------------------------------
+
+    def encode_batch(self, imgs, out=None):
+        """imgs: (B,3,H,W), H and W multiples of 2**num_scales, values 0..255 (any dtype / device).
+        Enqueues the whole encode on the current stream and returns an EncodedBatch (no host sync).
+        `out`: a network output for `imgs` computed earlier (avoids a second forward)."""
+        net = self.blueprint.net
+        fac = 2 ** net.config_ms.num_scales
+        B, _, H, W = imgs.shape
+        assert H % fac == 0 and W % fac == 0, 'pad first: {}x{} not divisible by {}'.format(H, W, fac)
+        if out is None:
+            out = net(imgs.to('cuda', torch.float32))
+        raw = out.raw
+        K = net.config_ms.prob.K
+        enc = EncodedBatch(B, (H, W))
+        for scale, dmll, uniform in self.iter_scale_dmll():
+            sym = raw.sym[scale]
+            _, C, Hs, Ws = sym.shape
+            if uniform:
+                iv = ops.intervals_from_table(self._uniform_row(dmll.L), sym.reshape(B * C, Hs * Ws), B * C, Hs * Ws,
+                                              broadcast_row=True)
+            else:
+                iv = ops.dmll_encode_intervals(raw.P[scale], sym, self._targets(dmll), C, K, dmll.rgb_scale)
+            stream_bytes, nbytes = ops.ac_encode(iv, B * C, Hs * Ws)
+            enc.scales.append((C, Hs, Ws, stream_bytes, nbytes))
+        return enc
+
+    def decode_batch(self, files):
+        """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU,
+        list of padding tuples)."""
+        net = self.blueprint.net
+        K = net.config_ms.prob.K
+        B = len(files)
+        readers = [_Reader(f) for f in files]
+        padding = [r.unpack('<4H') for r in readers]
+        bn_prev, F_prev, sym = None, None, None
+        for scale, dmll, uniform in self.iter_scale_dmll():
+            shapes = {r.unpack('<BHH') for r in readers}
+            if len(shapes) != 1:
+                raise ValueError('decode_batch needs equally sized images, got shapes {}'.format(sorted(shapes)))
+            C, H, W = shapes.pop()
+            payloads = []           # stream order b*C + c
+            for r in readers:
+                for _ in range(C):
+                    n, = r.unpack('<I')
+                    payloads.append(r.take(n))
+            for r in readers:
+                if r.take(4) != _MAGIC_VALUE_SEP:
+                    raise ValueError('invalid file: scale separator missing')
+            if uniform:
+                assert bn_prev is None
+                buf, offs, lens = ops.pack_streams(payloads)
+                sym = ops.ac_decode(self._uniform_row(dmll.L), buf, offs, lens, B * C, H * W, True,
+                                    broadcast_row=True).reshape(B, C, H, W)
+            else:
+                P, F_prev = net.get_P(scale, bn_prev, F_prev)
+                P = ops.as_pixel_major(P)
+                targets = self._targets(dmll)
+                if dmll.rgb_scale:
+                    # R -> G -> B: channel c's means depend on the decoded values of channels < c
+                    sym = torch.zeros(B, C, H, W, dtype=torch.int16, device='cuda')
+                    for c in range(C):
+                        pi, mu, ls = ops.dmll_channel_params(P, sym, C, K, True, c)
+                        table, flag = ops.cdf_table_mixture(targets, pi, mu, ls)
+                        buf, offs, lens = ops.pack_streams(payloads[c::C])
+                        sym[:, c] = ops.ac_decode(table.reshape(B * H * W, -1), buf, offs, lens, B, H * W,
+                                                  int(flag.item()) == 0).reshape(B, H, W)
+                else:
+                    params = [ops.dmll_channel_params(P, None, C, K, False, c) for c in range(C)]
+                    pi, mu, ls = [torch.stack([p[i] for p in params], dim=1).reshape(B * C, K, H, W) for i in range(3)]
+                    table, flag = ops.cdf_table_mixture(targets, pi, mu, ls)
+                    buf, offs, lens = ops.pack_streams(payloads)
+                    sym = ops.ac_decode(table.reshape(B * C * H * W, -1), buf, offs, lens, B * C, H * W,
+                                        int(flag.item()) == 0).reshape(B, C, H, W)
+            bn_prev = ops.sym_to_bn(sym, dmll.bin_width, dmll.x_min)
+        assert bn_prev is not None
+        return bn_prev.round().long(), padding
+
+    # ---- reference API: one image <-> one file -----------------------------------------------------------------------
+
+    def encode(self, img, pout):
+        """Encode image to disk at path `pout`.  img: int64 tensor CHW or 1CHW.  Returns the actual bpsp."""
+        assert not os.path.isfile(pout)
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        assert img.dim() == 4 and img.shape[0] == 1 and img.shape[1] == 3, img.shape
+        assert img.dtype == torch.int64, img.dtype
+
+        if auto_crop.needs_crop(img):
+            print('Need to encode individual crops!')
+            comb = auto_crop.CropLossCombinator()
+            for i, crop in enumerate(auto_crop.iter_crops(img)):
+                bpsp_crop = self.encode(crop, pout + part_suffix_helper.make_part_suffix(i))
+                comb.add(bpsp_crop, int(np.prod(crop.shape[-2:])))
+            return comb.get_bpsp()
+
+        fac = 2 ** self.blueprint.net.config_ms.num_scales
+        _, _, H, W = img.shape
+        if H % fac != 0 or W % fac != 0:
+            print('*** INFO: image shape ({}X{}) not divisible by {}, will pad.'.format(H, W, fac))
+            img, padding_tuple = pad.pad(img, fac=fac, mode=self.blueprint.get_padding_mode())
+        else:
+            padding_tuple = (0, 0, 0, 0)
+
+        with self.times.run('[-] encode forwardpass'):
+            out = self.blueprint.net(img.to('cuda', torch.float32))
+        loss_out = self.blueprint.get_loss(out) if self.compare_with_theory else None
+        enc = self.encode_batch(img, out=out)
+        data = enc.to_bytes([padding_tuple])[0]
+        with open(pout, 'wb') as fout:
+            fout.write(data)
+
+        num_subpixels = int(np.prod(img.shape))
+        actual_bpsp = len(data) * 8 / num_subpixels
+        if self.compare_with_theory:
+            per_scale = [int(n.sum().item()) * 8 / num_subpixels for _, _, _, _, n in enc.scales]
+            tostr = lambda l: ' | '.join(map('{:.3f}'.format, l)) + ' => {:.3f}'.format(sum(l))   # noqa: E731
+            theory = [float(b) for b in loss_out.nonrecursive_bpsps]
+            overhead = (sum(per_scale) / sum(theory) - 1) * 100
+            print('Bitrates:\ntheory:  {}\nassumed: {} [{:.2f}%]\nactual:                                => {:.3f} '
+                  '[{} bytes]'.format(tostr(theory), tostr(list(reversed(per_scale))), overhead, actual_bpsp, len(data)))
+        return actual_bpsp
+
+    def decode(self, pin, _recurse_part=True):
+        """-> decoded image, 1CHW long (on the GPU)."""
+        if _recurse_part and part_suffix_helper.contains_part_suffix(pin):
+            parts = [self.decode(p, _recurse_part=False) for p in part_suffix_helper.iter_part_suffixes(pin)]
+            print('Stitching {} parts...'.format(len(parts)))
+            return auto_crop.stitch(parts)
+        with open(pin, 'rb') as fin:
+            data = fin.read()
+        out, padding = self.decode_batch([data])
+        if any(padding[0]):
+            out = pad.undo_pad(out, *padding[0])
+        return out
+
+
+class _Reader(object):
+    def __init__(self, data):
+        self.d, self.p = data, 0
+
+    def take(self, n):
+        b = self.d[self.p:self.p + n]
+        if len(b) != n:
+            raise ValueError('invalid file: truncated')
+        self.p += n
+        return b
+
+    def unpack(self, fmt):
+        return struct.unpack(fmt, self.take(struct.calcsize(fmt)))

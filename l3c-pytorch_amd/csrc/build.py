@@ -1,0 +1,56 @@
+"""Build libl3c_hip.so for gfx950 with hipcc (cross-compiles without a GPU), in-tree next to the sources.
+
+    python l3c-pytorch_amd/csrc/build.py [--force] [--verbose]
+
+-ffp-contract=off: every fp32 op of the mixture head is individually rounded so that the encoder's fused interval
+kernel and the decoder's table kernel produce identical entries (dmll_kernels.hip); kernels that want an FMA say fmaf().
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip']
+HEADERS = ['ac_core.h', 'l3c_common.h', os.path.join('..', '..', 'include', 'l3c_hip.h')]
+LIB = os.path.join(HERE, 'libl3c_hip.so')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+
+
+def _stale(target, deps):
+    if not os.path.isfile(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    objs = []
+    hdrs = [os.path.join(HERE, h) for h in HEADERS]
+    os.makedirs(os.path.join(HERE, '_obj'), exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(HERE, '_obj', src.replace('.hip', '.o'))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', s, '-o', o]
+            if verbose:
+                print(' '.join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed on {}:\n{}'.format(src, out.decode()))
+        if verbose and out:
+            print(out.decode())
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv))

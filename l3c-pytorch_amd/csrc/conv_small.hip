@@ -1,0 +1,194 @@
+// conv_small.hip -- the thin (3-, 5-channel) ends of the conv stack; all HBM-bound, no MFMA.
+//
+//   rgb_head_kernel      sub_rgb_mean -> MeanShift(1/128) -> conv3x3 3->Cf      (multiscale_network.py:241, head.py:26-41)
+//   to_q_quantize_kernel conv1x1 Cf->C + hard quantiser                          (net.py:144-148, quantizer.py:72-87)
+//   dec_head_kernel      conv1x1 C->Cf (+ fused coarser features)                (net.py:178-180)
+//   sym_to_bn_kernel     to_bn                                                   (quantizer.py:44-47)
+// Wide tensors are pixel-major: 16 consecutive lanes own the 64 channels of one pixel as float4s, so a wavefront
+// reads/writes 4 pixels x 256 B = 1 KB contiguous per instruction.
+#include "l3c_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int RH_TH = 8, RH_TW = 32;
+
+__global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__ img, const float *__restrict__ w1,
+                                                       const float *__restrict__ b1, const float *__restrict__ w2,
+                                                       const float *__restrict__ b2, const float *__restrict__ w3,
+                                                       const float *__restrict__ b3, int H, int W, int Cf,
+                                                       float *__restrict__ out, float *__restrict__ shifted_out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *s_w = smem;                                   // [27][Cf]  (tap-major: (ky*3+kx)*3 + ci)
+    float *s_in = smem + 27 * Cf;                        // [3][RH_TH+2][RH_TW+2]
+    constexpr int IH = RH_TH + 2, IW = RH_TW + 2;
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int oy0 = blockIdx.y * RH_TH, ox0 = blockIdx.x * RH_TW;
+    for (int i = tid; i < 27 * Cf; i += 256) {
+        const int co = i % Cf, r = i / Cf;               // r = (ky*3+kx)*3 + ci
+        const int ci = r % 3, tap = r / 3;
+        s_w[i] = w3[((size_t)co * 3 + ci) * 9 + tap];
+    }
+    const size_t plane = (size_t)H * W;
+    const float *im = img + (size_t)b * 3 * plane;
+    for (int i = tid; i < IH * IW; i += 256) {
+        const int r = i / IW, c = i % IW;
+        const int y = oy0 + r - 1, x = ox0 + c - 1;
+        float z[3] = {0.f, 0.f, 0.f};
+        if (y >= 0 && y < H && x >= 0 && x < W) {
+            float v[3], u[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[k] = im[k * plane + (size_t)y * W + x];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) u[o] = ((v[0] * w1[o * 3 + 0] + v[1] * w1[o * 3 + 1]) + v[2] * w1[o * 3 + 2]) + b1[o];
+#pragma unroll
+            for (int o = 0; o < 3; ++o) z[o] = ((u[0] * w2[o * 3 + 0] + u[1] * w2[o * 3 + 1]) + u[2] * w2[o * 3 + 2]) + b2[o];
+            if (shifted_out && r >= 1 && r <= RH_TH && c >= 1 && c <= RH_TW) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) shifted_out[((size_t)b * 3 + o) * plane + (size_t)y * W + x] = z[o];
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) s_in[(o * IH + r) * IW + c] = z[o];
+    }
+    __syncthreads();
+    const int quads = Cf / 4;                            // 16 lanes per pixel when Cf == 64
+    const int q = tid % quads;
+    const int pix_per_pass = 256 / quads;
+    for (int pp = tid / quads; pp < RH_TH * RH_TW; pp += pix_per_pass) {
+        const int r = pp / RH_TW, c = pp % RH_TW;
+        const int y = oy0 + r, x = ox0 + c;
+        if (y >= H || x >= W) continue;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float v = s_in[(ci * IH + r + ky) * IW + c + kx];
+                    const f32x4 wv = *reinterpret_cast<const f32x4 *>(&s_w[((ky * 3 + kx) * 3 + ci) * Cf + q * 4]);
+                    acc = acc + v * wv;
+                }
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(&b3[q * 4]);
+        *reinterpret_cast<f32x4 *>(&out[(((size_t)b * H + y) * W + x) * Cf + q * 4]) = acc + bias;
+    }
+}
+
+__global__ __launch_bounds__(256) void to_q_quantize_kernel(const float *__restrict__ feat, const float *__restrict__ w,
+                                                            const float *__restrict__ bias, const float *__restrict__ levels,
+                                                            int64_t B, int64_t HW, int Cf, int C, int L,
+                                                            int16_t *__restrict__ sym, float *__restrict__ bn_q,
+                                                            float *__restrict__ bn) {
+    const int64_t total = B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, n = i % HW;
+        const f32x4 *px = reinterpret_cast<const f32x4 *>(feat + i * Cf);
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.0f;
+        for (int k4 = 0; k4 < Cf / 4; ++k4) {
+            const f32x4 v = px[k4];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < C) {
+                    const float *wc = w + c * Cf + k4 * 4;
+                    acc[c] = fmaf(v[3], wc[3], fmaf(v[2], wc[2], fmaf(v[1], wc[1], fmaf(v[0], wc[0], acc[c]))));
+                }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c < C) {
+                const float x = acc[c] + bias[c];
+                int best = 0;
+                float dbest = (x - levels[0]) * (x - levels[0]);
+                for (int l = 1; l < L; ++l) {
+                    const float d = (x - levels[l]) * (x - levels[l]);
+                    if (d < dbest) {   // first minimum wins (torch.min)
+                        dbest = d;
+                        best = l;
+                    }
+                }
+                const int64_t o = (b * C + c) * HW + n;
+                sym[o] = (int16_t)best;
+                bn_q[o] = levels[best];
+                if (bn) bn[o] = x;
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__ bn_q, const float *__restrict__ w,
+                                                       const float *__restrict__ bias, const float *__restrict__ fuse,
+                                                       int64_t B, int64_t HW, int C, int Cf, float *__restrict__ out) {
+    const int quads = Cf / 4;
+    const int64_t total = B * HW * quads;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % quads);
+        const int64_t pix = i / quads;
+        const int64_t b = pix / HW, n = pix % HW;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            const float v = bn_q[(b * C + c) * HW + n];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = fmaf(v, w[(q * 4 + j) * C + c], acc[j]);
+        }
+        f32x4 r = acc + *reinterpret_cast<const f32x4 *>(&bias[q * 4]);
+        if (fuse) r = r + *reinterpret_cast<const f32x4 *>(&fuse[pix * Cf + q * 4]);
+        *reinterpret_cast<f32x4 *>(&out[pix * Cf + q * 4]) = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void sym_to_bn_kernel(const int16_t *__restrict__ sym, int64_t n, float bin_width,
+                                                        float x_min, float *__restrict__ bn) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        bn[i] = (float)sym[i] * bin_width + x_min;   // two roundings (file is built with -ffp-contract=off)
+}
+
+int grid_1d(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3c_rgb_head(const float *img, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
+                 const float *b3, int B, int H, int W, int Cf, float *out, float *shifted_out, l3c_stream_t stream) {
+    L3C_REQUIRE(img && w1 && b1 && w2 && b2 && w3 && b3 && out, "null pointer");
+    L3C_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, "bad shape");
+    L3C_REQUIRE(Cf % 4 == 0 && Cf >= 4 && Cf <= 256 && 256 % (Cf / 4) == 0, "Cf must be 4 * a divisor of 256");
+    const size_t lds = (size_t)(27 * Cf + 3 * (RH_TH + 2) * (RH_TW + 2)) * sizeof(float);
+    const dim3 grid((unsigned)((W + RH_TW - 1) / RH_TW), (unsigned)((H + RH_TH - 1) / RH_TH), (unsigned)B);
+    hipLaunchKernelGGL(rgb_head_kernel, grid, dim3(256), lds, l3c::as_stream(stream), img, w1, b1, w2, b2, w3, b3, H, W,
+                       Cf, out, shifted_out);
+    return l3c::check_launch("rgb_head_kernel");
+}
+
+int l3c_to_q_quantize(const float *feat, const float *w, const float *b, const float *levels, int64_t B, int64_t HW,
+                      int Cf, int C, int L, int16_t *sym, float *bn_q, float *bn, l3c_stream_t stream) {
+    L3C_REQUIRE(feat && w && b && levels && sym && bn_q, "null pointer");
+    L3C_REQUIRE(B > 0 && HW > 0 && Cf % 4 == 0 && C > 0 && C <= 8 && L > 0 && L <= 32767, "bad shape (C <= 8)");
+    hipLaunchKernelGGL(to_q_quantize_kernel, dim3(grid_1d(B * HW, 256)), dim3(256), 0, l3c::as_stream(stream), feat, w, b,
+                       levels, B, HW, Cf, C, L, sym, bn_q, bn);
+    return l3c::check_launch("to_q_quantize_kernel");
+}
+
+int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float *fuse, int64_t B, int64_t HW, int C,
+                 int Cf, float *out, l3c_stream_t stream) {
+    L3C_REQUIRE(bn_q && w && b && out, "null pointer");
+    L3C_REQUIRE(B > 0 && HW > 0 && C > 0 && Cf % 4 == 0, "bad shape");
+    hipLaunchKernelGGL(dec_head_kernel, dim3(grid_1d(B * HW * (Cf / 4), 256)), dim3(256), 0, l3c::as_stream(stream), bn_q,
+                       w, b, fuse, B, HW, C, Cf, out);
+    return l3c::check_launch("dec_head_kernel");
+}
+
+int l3c_sym_to_bn(const int16_t *sym, int64_t n, float bin_width, float x_min, float *bn, l3c_stream_t stream) {
+    L3C_REQUIRE(sym && bn && n > 0, "bad arguments");
+    hipLaunchKernelGGL(sym_to_bn_kernel, dim3(grid_1d(n, 256)), dim3(256), 0, l3c::as_stream(stream), sym, n, bin_width,
+                       x_min, bn);
+    return l3c::check_launch("sym_to_bn_kernel");
+}
+}

@@ -1,0 +1,333 @@
+// dmll_kernels.hip -- discretised logistic-mixture head on the GPU.
+//
+// Replaces, on the coding path: criterion/logistic_mixture.py (_extract_non_shared_c :248-275, cdf_step_non_shared
+// :134-141, forward :146-207) and torchac_kernel.cu (calculate_cdf_kernel :26-76 == torchac.py:_get_uint16_cdf :174-213).
+//
+// Bit-reproducibility contract: the encoder never materialises a table (l3c_dmll_encode_intervals evaluates only the two
+// entries per symbol that the coder reads) while the decoder does (l3c_dmll_channel_params -> l3c_cdf_table_mixture ->
+// l3c_ac_decode).  Both go through the SAME device functions below (mix_stats / mix_component / cdf_entry), every
+// floating-point operation is an individually rounded fp32 op in a fixed order (this file is compiled with
+// -ffp-contract=off, K is walked sequentially, no atomics), so the two paths produce identical table entries.
+//
+// Arithmetic follows the torch-CPU statement of the reference kernel (which is what the oracle pins):
+//   pi  = exp(l - max) / sum_k exp(l - max)            F.softmax(dim=K)
+//   mu' = mu (+ sigmoid(lam) * x_prev ...)              logistic_mixture.py:262-272
+//   ls  = max(log_sigma, -7)                            :260
+//   cdf(l) = sum_k pi_k * sigmoid((t_l - mu'_k) * exp(-ls_k))   sequential k, mul then add   (torchac.py:181-200)
+//   entry  = uint16(rint(cdf * (65536 - (Lp-1))) + l)            round-half-even, wraps mod 2^16 (torchac.py:203-213)
+#include "ac_core.h"
+#include "l3c_common.h"
+
+namespace {
+
+constexpr float kLogScalesMin = -7.0f;
+
+__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + expf(-a)); }
+
+// Accessor concept: float operator()(int ch) -- channel `ch` (0..Kp-1) of the current pixel.
+
+struct MixStats {
+    float max_logit, denom;
+};
+
+template <class Get>
+__device__ __forceinline__ MixStats mix_stats(Get get, int C, int K, int c) {
+    MixStats s;
+    s.max_logit = get(c * K);
+    for (int k = 1; k < K; ++k) s.max_logit = fmaxf(s.max_logit, get(c * K + k));
+    s.denom = 0.0f;
+    for (int k = 0; k < K; ++k) s.denom = s.denom + expf(get(c * K + k) - s.max_logit);
+    return s;
+}
+
+struct MixComponent {
+    float pi, mu, log_sigma;
+};
+
+// x0, x1: actual values of the previously coded channels (RGB scale only, c > 0).
+template <class Get>
+__device__ __forceinline__ MixComponent mix_component(Get get, const MixStats &st, int C, int K, int rgb, int c, int k,
+                                                      float x0, float x1) {
+    const int CK = C * K;
+    MixComponent m;
+    m.pi = expf(get(c * K + k) - st.max_logit) / st.denom;
+    m.mu = get(CK + c * K + k);
+    m.log_sigma = fmaxf(get(2 * CK + c * K + k), kLogScalesMin);
+    if (rgb && c == 1) {
+        m.mu = m.mu + sigmoid_f(get(3 * CK + k)) * x0;
+    } else if (rgb && c == 2) {
+        const float a = sigmoid_f(get(3 * CK + K + k)) * x0;
+        const float b = sigmoid_f(get(3 * CK + 2 * K + k)) * x1;
+        m.mu = m.mu + (a + b);
+    }
+    return m;
+}
+
+__device__ __forceinline__ float cdf_term(float pi, float mu, float inv_sigma, float target) {
+    return pi * sigmoid_f((target - mu) * inv_sigma);
+}
+
+__device__ __forceinline__ uint32_t cdf_quantise(float cdf, float scale, int l) {
+    return (uint32_t)((int)rintf(cdf * scale) + l) & 0xFFFFu;
+}
+
+// ---- per-channel parameters (CDFOut) ---------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void channel_params_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
+                                                             int64_t B, int64_t HW, int C, int K, int rgb, int c,
+                                                             float *__restrict__ pi, float *__restrict__ mu,
+                                                             float *__restrict__ log_sigma) {
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const int64_t total = B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, n = i % HW;
+        const float *px = P + i * Kp;
+        auto get = [&](int ch) { return px[ch]; };
+        float x0 = 0.f, x1 = 0.f;
+        if (rgb && c > 0) {
+            x0 = (float)sym[(b * C + 0) * HW + n];
+            if (c > 1) x1 = (float)sym[(b * C + 1) * HW + n];
+        }
+        const MixStats st = mix_stats(get, C, K, c);
+        for (int k = 0; k < K; ++k) {
+            const MixComponent m = mix_component(get, st, C, K, rgb, c, k, x0, x1);
+            const int64_t o = (b * K + k) * HW + n;
+            pi[o] = m.pi;
+            mu[o] = m.mu;
+            log_sigma[o] = m.log_sigma;
+        }
+    }
+}
+
+// ---- full uint16 table (decoder side; the reference's calculate_cdf_kernel) -------------------------------------------
+
+constexpr int kTablePix = 32;  // pixels per block
+constexpr int kMaxK = 16;
+
+__global__ __launch_bounds__(256) void cdf_table_kernel(const float *__restrict__ targets, const float *__restrict__ pi,
+                                                        const float *__restrict__ mu, const float *__restrict__ ls,
+                                                        int64_t HW, int K, int Lp, uint16_t *__restrict__ cdf) {
+    __shared__ float s_pi[kTablePix][kMaxK], s_mu[kTablePix][kMaxK], s_inv[kTablePix][kMaxK];
+    __shared__ float s_t[260];
+    const int64_t img = blockIdx.y;
+    const int64_t pix0 = (int64_t)blockIdx.x * kTablePix;
+    const int npix = (int)((HW - pix0) < kTablePix ? (HW - pix0) : kTablePix);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < kTablePix * K; i += 256) {
+        const int p = i % kTablePix, k = i / kTablePix;
+        if (p < npix) {
+            const int64_t o = (img * K + k) * HW + pix0 + p;
+            s_pi[p][k] = pi[o];
+            s_mu[p][k] = mu[o];
+            s_inv[p][k] = expf(-ls[o]);
+        }
+    }
+    for (int i = tid; i < Lp; i += 256) s_t[i] = targets[i];
+    __syncthreads();
+    const float scale = (float)(65536 - (Lp - 1));
+    const int count = npix * Lp;
+    uint16_t *out = cdf + (img * HW + pix0) * Lp;
+    const bool aligned4 = ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+    for (int e = tid * 2; e < count; e += 512) {
+        uint32_t v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ee = e + h < count ? e + h : e;
+            const int p = ee / Lp, l = ee - p * Lp;
+            const float t = s_t[l];
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = acc + cdf_term(s_pi[p][k], s_mu[p][k], s_inv[p][k], t);
+            v[h] = cdf_quantise(acc, scale, l);
+        }
+        if (aligned4 && e + 1 < count) {
+            *reinterpret_cast<uint32_t *>(out + e) = v[0] | (v[1] << 16);
+        } else {
+            out[e] = (uint16_t)v[0];
+            if (e + 1 < count) out[e + 1] = (uint16_t)v[1];
+        }
+    }
+}
+
+// ---- fused encoder head: P + symbols -> packed coding intervals -------------------------------------------------------
+
+constexpr int kHeadPix = 64;  // == interval block length, so one block writes whole 256-byte interval runs
+
+__global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
+                                                               const float *__restrict__ targets, int64_t HW, int C, int K,
+                                                               int rgb, int Lp, uint32_t *__restrict__ iv) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [kHeadPix][Kp + 1]
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const int ld = Kp + 1;
+    const int64_t b = blockIdx.y;
+    const int64_t chunk = blockIdx.x;
+    const int64_t pix0 = chunk * kHeadPix;
+    const int npix = (int)((HW - pix0) < kHeadPix ? (HW - pix0) : kHeadPix);
+    const int tid = threadIdx.x;
+    const float *src = P + (b * HW + pix0) * Kp;
+    for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+    __syncthreads();
+    const float scale = (float)(65536 - (Lp - 1));
+    const int64_t n_streams = (int64_t)gridDim.y * C;
+    for (int w = tid; w < kHeadPix * C; w += 256) {
+        const int p = w % kHeadPix, c = w / kHeadPix;
+        uint32_t word = 0;
+        if (p < npix) {
+            const float *px = tile + p * ld;
+            auto get = [&](int ch) { return px[ch]; };
+            const int64_t n = pix0 + p;
+            const int x = sym[(b * C + c) * HW + n];
+            float x0 = 0.f, x1 = 0.f;
+            if (rgb && c > 0) {
+                x0 = (float)sym[(b * C + 0) * HW + n];
+                if (c > 1) x1 = (float)sym[(b * C + 1) * HW + n];
+            }
+            const float t_lo = targets[x];
+            const float t_hi = targets[x + 1];
+            const MixStats st = mix_stats(get, C, K, c);
+            float acc_lo = 0.0f, acc_hi = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                const MixComponent m = mix_component(get, st, C, K, rgb, c, k, x0, x1);
+                const float inv = expf(-m.log_sigma);
+                acc_lo = acc_lo + cdf_term(m.pi, m.mu, inv, t_lo);
+                acc_hi = acc_hi + cdf_term(m.pi, m.mu, inv, t_hi);
+            }
+            const uint32_t c_lo = cdf_quantise(acc_lo, scale, x);
+            const uint32_t c_hi = (x == Lp - 2) ? 0x10000u : cdf_quantise(acc_hi, scale, x + 1);
+            word = l3c::pack_interval(c_lo, c_hi);
+        }
+        iv[(chunk * n_streams + b * C + c) * kHeadPix + p] = word;
+    }
+}
+
+// ---- negative log-likelihood map ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.0f ? x : log1pf(expf(x)); }  // F.softplus defaults
+
+__global__ __launch_bounds__(256) void nll_kernel(const float *__restrict__ P, const float *__restrict__ xs, int64_t HW,
+                                                  int C, int K, int rgb, float x_lower, float x_upper, float half_bin,
+                                                  float *__restrict__ nll) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const int CK = C * K;
+    const int ld = Kp + 1;
+    const int64_t b = blockIdx.y;
+    const int64_t pix0 = (int64_t)blockIdx.x * kHeadPix;
+    const int npix = (int)((HW - pix0) < kHeadPix ? (HW - pix0) : kHeadPix);
+    const int tid = threadIdx.x;
+    const float *src = P + (b * HW + pix0) * Kp;
+    for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+    __syncthreads();
+    for (int w = tid; w < kHeadPix * C; w += 256) {
+        const int p = w % kHeadPix, c = w / kHeadPix;
+        if (p >= npix) continue;
+        const float *px = tile + p * ld;
+        const int64_t n = pix0 + p;
+        const float x = xs[(b * C + c) * HW + n];
+        float x0 = 0.f, x1 = 0.f;
+        if (rgb && c > 0) {
+            x0 = xs[(b * C + 0) * HW + n];
+            if (c > 1) x1 = xs[(b * C + 1) * HW + n];
+        }
+        // log_softmax over K of the mixture logits (logistic_mixture.py:334-337)
+        float m = px[c * K];
+        for (int k = 1; k < K; ++k) m = fmaxf(m, px[c * K + k]);
+        float se = 0.0f;
+        for (int k = 0; k < K; ++k) se = se + expf(px[c * K + k] - m);
+        const float lse = logf(se);
+        // first pass: weighted log-probs, keep their max; second pass: log-sum-exp (:340-345)
+        float lp[kMaxK];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k) {
+            if (k < K) {
+                float mu = px[CK + c * K + k];
+                if (rgb && c == 1) mu = mu + sigmoid_f(px[3 * CK + k]) * x0;
+                if (rgb && c == 2) mu = (mu + sigmoid_f(px[3 * CK + K + k]) * x0) + sigmoid_f(px[3 * CK + 2 * K + k]) * x1;
+                const float inv = expf(-fmaxf(px[2 * CK + c * K + k], kLogScalesMin));
+                const float centered = x - mu;
+                const float plus_in = inv * (centered + half_bin);
+                const float min_in = inv * (centered - half_bin);
+                const float delta = sigmoid_f(plus_in) - sigmoid_f(min_in);
+                float lprob = logf(fmaxf(delta, 1e-12f));
+                if (x > x_upper) lprob = -softplus_f(min_in);
+                if (x < x_lower) lprob = plus_in - softplus_f(plus_in);
+                lp[k] = lprob + ((px[c * K + k] - m) - lse);
+                mx = fmaxf(mx, lp[k]);
+            }
+        }
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kMaxK; ++k)
+            if (k < K) s = s + expf(lp[k] - mx);
+        nll[(b * C + c) * HW + n] = -(logf(s) + mx);
+    }
+}
+
+int grid_1d(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3c_dmll_channel_params(const float *P, const int16_t *sym, int64_t B, int64_t HW, int C, int K, int rgb, int c,
+                            float *pi, float *mu, float *log_sigma, l3c_stream_t stream) {
+    L3C_REQUIRE(P && pi && mu && log_sigma, "null pointer");
+    L3C_REQUIRE(B > 0 && HW > 0 && C > 0 && K > 0 && c >= 0 && c < C, "bad shape");
+    L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3 (logistic_mixture.py:44-51)");
+    L3C_REQUIRE(!(rgb && c > 0) || sym, "sym required for the RGB scale, c > 0");
+    hipLaunchKernelGGL(channel_params_kernel, dim3(grid_1d(B * HW, 256)), dim3(256), 0, l3c::as_stream(stream), P, sym,
+                       B, HW, C, K, rgb, c, pi, mu, log_sigma);
+    return l3c::check_launch("channel_params_kernel");
+}
+
+int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu, const float *log_sigma, int64_t n_img,
+                          int64_t HW, int K, int Lp, uint16_t *cdf, int32_t *not_monotone, l3c_stream_t stream) {
+    L3C_REQUIRE(targets && pi && mu && log_sigma && cdf, "null pointer");
+    L3C_REQUIRE(n_img > 0 && n_img < 65536 && HW > 0, "bad shape");
+    L3C_REQUIRE(K > 0 && K <= kMaxK, "K out of range (1..16)");
+    L3C_REQUIRE(Lp >= 2 && Lp <= 260, "Lp out of range (2..260)");
+    const dim3 grid((unsigned)((HW + kTablePix - 1) / kTablePix), (unsigned)n_img);
+    hipLaunchKernelGGL(cdf_table_kernel, grid, dim3(256), 0, l3c::as_stream(stream), targets, pi, mu, log_sigma, HW, K,
+                       Lp, cdf);
+    int rc = l3c::check_launch("cdf_table_kernel");
+    if (rc == L3C_OK && not_monotone) rc = l3c_cdf_check_monotone(cdf, n_img * HW, Lp, not_monotone, stream);
+    return rc;
+}
+
+int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C,
+                              int K, int rgb, int Lp, uint32_t *intervals, l3c_stream_t stream) {
+    L3C_REQUIRE(P && sym && targets && intervals, "null pointer");
+    L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && K > 0, "bad shape");
+    L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
+    L3C_REQUIRE(Lp >= 2 && Lp <= 65536, "Lp out of range");
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const size_t lds = (size_t)kHeadPix * (Kp + 1) * sizeof(float);
+    L3C_REQUIRE(lds <= 64 * 1024, "Kp too large for the LDS tile");
+    const dim3 grid((unsigned)((HW + kHeadPix - 1) / kHeadPix), (unsigned)B);
+    hipLaunchKernelGGL(encode_intervals_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K,
+                       rgb, Lp, intervals);
+    return l3c::check_launch("encode_intervals_kernel");
+}
+
+int l3c_dmll_nll(const float *P, const float *x, int64_t B, int64_t HW, int C, int K, int rgb, float x_min, float x_max,
+                 int L, float *nll, l3c_stream_t stream) {
+    L3C_REQUIRE(P && x && nll, "null pointer");
+    L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0, "bad shape");
+    L3C_REQUIRE(K > 0 && K <= kMaxK, "K out of range (1..16)");
+    L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
+    L3C_REQUIRE(L >= 2, "L out of range");
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const size_t lds = (size_t)kHeadPix * (Kp + 1) * sizeof(float);
+    L3C_REQUIRE(lds <= 64 * 1024, "Kp too large for the LDS tile");
+    // bounds and half bin exactly as logistic_mixture.py:113-116 computes them (in double), then to fp32
+    const double bin = ((double)x_max - (double)x_min) / (double)(L - 1);
+    const float x_lower = (float)((double)x_min + 0.001), x_upper = (float)((double)x_max - 0.001);
+    const dim3 grid((unsigned)((HW + kHeadPix - 1) / kHeadPix), (unsigned)B);
+    hipLaunchKernelGGL(nll_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, x, HW, C, K, rgb, x_lower, x_upper,
+                       (float)(bin / 2.0), nll);
+    return l3c::check_launch("nll_kernel");
+}
+}

@@ -1,0 +1,211 @@
+"""Tensor-level wrappers of the HIP entry points (include/l3c_hip.h).  torch is only the owner of device memory and of
+the current stream here; every function enqueues kernels from libl3c_hip.so and nothing else."""
+import os
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, ptr, stream
+
+_CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU cross-check kernel (debugging)
+
+# Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
+# appends (kernel key, algorithmic FLOPs, start event, end event), the events being recorded on the launch stream.
+PROFILE = None
+
+
+# ---- convolution stack ------------------------------------------------------------------------------------------------
+
+
+class PackedConv(object):
+    """One conv layer resident on the device: OIHW weights, bias, and the MFMA-fragment-packed copy."""
+
+    def __init__(self, weight, bias, stride=1, dilation=1):
+        _lib.require_gpu()
+        self.Cout, self.Cin, self.KS, _ = weight.shape
+        self.stride, self.dilation = stride, dilation
+        self.weight = weight.detach().to('cuda', torch.float32).contiguous()
+        self.bias = bias.detach().to('cuda', torch.float32).contiguous()
+        self.packed = None
+        if self.Cin % 16 == 0:
+            n = _lib.load().l3c_conv_packed_words(self.Cout, self.Cin, self.KS)
+            self.packed = torch.empty(n, dtype=torch.float32, device='cuda')
+            call('l3c_conv_pack_weights', ptr(self.weight), self.Cout, self.Cin, self.KS, ptr(self.packed), stream())
+
+    def out_hw(self, H, W):
+        pad = self.KS // 2 if self.dilation == 1 else self.dilation
+        ext = (self.KS - 1) * self.dilation + 1
+        return (H + 2 * pad - ext) // self.stride + 1, (W + 2 * pad - ext) // self.stride + 1
+
+
+def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, relu=False, pixel_shuffle=False,
+         impl=None):
+    """x: (B,H,W,cstride) pixel-major fp32.  Returns `out` ((B,Ho,Wo,Cout) freshly allocated when None)."""
+    B, H, W, cstride = x.shape
+    Ho, Wo = layer.out_hw(H, W)
+    if out is None:
+        out = (torch.empty(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
+               else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
+    impl = impl or _CONV_IMPL
+    d = ConvDesc()
+    d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
+    d.packed_w = ptr(layer.packed if impl == 'mfma' else layer.weight)
+    d.bias = ptr(layer.bias)
+    d.residual = ptr(residual, torch.float32) if residual is not None else None
+    d.res_cstride = residual.shape[-1] if residual is not None else 0
+    d.res_coff = res_coff
+    d.out, d.out_cstride, d.out_coff = ptr(out, torch.float32), out.shape[-1], out_coff
+    d.B, d.Hin, d.Win, d.Cin, d.Cout = B, H, W, layer.Cin, layer.Cout
+    d.KS, d.stride, d.dilation = layer.KS, layer.stride, layer.dilation
+    d.epilogue = ((_lib.EPI_RELU if relu else 0) | (_lib.EPI_RESIDUAL if residual is not None else 0) |
+                  (_lib.EPI_PIXEL_SHUFFLE if pixel_shuffle else 0))
+    if PROFILE is not None and impl == 'mfma':
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call('l3c_conv_mfma', d, stream())
+        e1.record()
+        key = 'conv_mfma<k{},s{},d{}>'.format(layer.KS, layer.stride, layer.dilation)
+        PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, e0, e1))
+        return out
+    call('l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
+    return out
+
+
+def rgb_head(img, ms1_w, ms1_b, ms2_w, ms2_b, conv_w, conv_b, want_shifted=False):
+    """img (B,3,H,W) planar 0..255 -> (B,H,W,Cf) pixel-major features [, (B,3,H,W) mean-shifted image]."""
+    B, _, H, W = img.shape
+    Cf = conv_w.shape[0]
+    out = torch.empty(B, H, W, Cf, dtype=torch.float32, device=img.device)
+    shifted = torch.empty_like(img) if want_shifted else None
+    call('l3c_rgb_head', ptr(img, torch.float32), ptr(ms1_w), ptr(ms1_b), ptr(ms2_w), ptr(ms2_b), ptr(conv_w),
+         ptr(conv_b), B, H, W, Cf, ptr(out), ptr(shifted), stream())
+    return (out, shifted) if want_shifted else out
+
+
+def to_q_quantize(feat, w, b, levels, want_bn=False):
+    """feat (B,H,W,Cf) -> sym int16 (B,C,H,W), bn_q fp32 (B,C,H,W) [, bn pre-quantisation]."""
+    B, H, W, Cf = feat.shape
+    C, L = w.shape[0], levels.shape[0]
+    sym = torch.empty(B, C, H, W, dtype=torch.int16, device=feat.device)
+    bn_q = torch.empty(B, C, H, W, dtype=torch.float32, device=feat.device)
+    bn = torch.empty_like(bn_q) if want_bn else None
+    call('l3c_to_q_quantize', ptr(feat, torch.float32), ptr(w), ptr(b), ptr(levels), B, H * W, Cf, C, L, ptr(sym),
+         ptr(bn_q), ptr(bn), stream())
+    return (sym, bn_q, bn) if want_bn else (sym, bn_q)
+
+
+def dec_head(bn_q, w, b, fuse=None):
+    """bn_q (B,C,H,W) planar -> (B,H,W,Cf) pixel-major, + fuse."""
+    B, C, H, W = bn_q.shape
+    Cf = w.shape[0]
+    out = torch.empty(B, H, W, Cf, dtype=torch.float32, device=bn_q.device)
+    call('l3c_dec_head', ptr(bn_q, torch.float32), ptr(w), ptr(b), ptr(fuse, torch.float32) if fuse is not None else None,
+         B, H * W, C, Cf, ptr(out), stream())
+    return out
+
+
+def sym_to_bn(sym, bin_width, x_min):
+    bn = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
+    call('l3c_sym_to_bn', ptr(sym, torch.int16), sym.numel(), float(bin_width), float(x_min), ptr(bn), stream())
+    return bn
+
+
+# ---- logistic-mixture head --------------------------------------------------------------------------------------------
+
+
+def as_pixel_major(l):
+    """(N,Kp,H,W) logical tensor -> (N,H,W,Kp) contiguous storage (free when `l` already is a permuted NHWC view)."""
+    return l.permute(0, 2, 3, 1).contiguous()
+
+
+def dmll_channel_params(P_nhwc, sym, C, K, rgb, c):
+    """-> pi, mu, log_sigma, each (B,K,H,W)."""
+    B, H, W, _ = P_nhwc.shape
+    outs = [torch.empty(B, K, H, W, dtype=torch.float32, device=P_nhwc.device) for _ in range(3)]
+    call('l3c_dmll_channel_params', ptr(P_nhwc, torch.float32), ptr(sym, torch.int16) if sym is not None else None,
+         B, H * W, C, K, int(rgb), c, ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), stream())
+    return outs
+
+
+def cdf_table_mixture(targets, pi, mu, log_sigma, check_monotone=True):
+    """params (B,K,H,W) -> uint16 table viewed as int16 (B,H,W,Lp); also returns the not-monotone flag tensor."""
+    B, K, H, W = pi.shape
+    Lp = targets.shape[0]
+    cdf = torch.empty(B, H, W, Lp, dtype=torch.int16, device=pi.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=pi.device) if check_monotone else None
+    call('l3c_cdf_table_mixture', ptr(targets, torch.float32), ptr(pi, torch.float32), ptr(mu, torch.float32),
+         ptr(log_sigma, torch.float32), B, H * W, K, Lp, ptr(cdf), ptr(flag), stream())
+    return cdf, flag
+
+
+def dmll_encode_intervals(P_nhwc, sym, targets, C, K, rgb):
+    """P (B,H,W,Kp), sym int16 (B,C,H,W) -> packed interval words for the B*C streams of this scale."""
+    B, H, W, _ = P_nhwc.shape
+    Lp = targets.shape[0]
+    n = _lib.load().l3c_interval_words(B * C, H * W)
+    iv = torch.empty(n, dtype=torch.int32, device=P_nhwc.device)
+    call('l3c_dmll_encode_intervals', ptr(P_nhwc, torch.float32), ptr(sym, torch.int16), ptr(targets, torch.float32),
+         B, H * W, C, K, int(rgb), Lp, ptr(iv), stream())
+    return iv
+
+
+def dmll_nll(P_nhwc, x, C, K, rgb, x_min, x_max, L):
+    """x (B,C,H,W) fp32 targets -> nll (B,C,H,W) in nats."""
+    B, H, W, _ = P_nhwc.shape
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=P_nhwc.device)
+    call('l3c_dmll_nll', ptr(P_nhwc, torch.float32), ptr(x, torch.float32), B, H * W, C, K, int(rgb), float(x_min),
+         float(x_max), L, ptr(out), stream())
+    return out
+
+
+# ---- arithmetic coder -------------------------------------------------------------------------------------------------
+
+
+def intervals_from_table(cdf, sym, n_streams, n_sym, broadcast_row=False):
+    """cdf int16/uint16: (n_streams*n_sym, Lp) rows, or one row (Lp,) with broadcast_row; sym int16 (n_streams, n_sym)."""
+    Lp = cdf.shape[-1]
+    n = _lib.load().l3c_interval_words(n_streams, n_sym)
+    iv = torch.empty(n, dtype=torch.int32, device=sym.device)
+    call('l3c_ac_intervals_from_table', ptr(cdf), 0 if broadcast_row else Lp, Lp, ptr(sym, torch.int16), n_streams,
+         n_sym, ptr(iv), stream())
+    return iv
+
+
+def ac_encode(iv, n_streams, n_sym):
+    """-> (out uint8 (n_streams, stride), nbytes int32 (n_streams,)) on the device."""
+    stride = _lib.load().l3c_ac_max_bytes(n_sym)
+    out = torch.empty(n_streams, stride, dtype=torch.uint8, device=iv.device)
+    nbytes = torch.empty(n_streams, dtype=torch.int32, device=iv.device)
+    call('l3c_ac_encode', ptr(iv), n_streams, n_sym, ptr(out), stride, ptr(nbytes), stream())
+    return out, nbytes
+
+
+def pack_streams(payloads, device='cuda'):
+    """list of bytes -> (uint8 buffer with every stream 4-byte aligned and zero padded, offsets int64, nbytes int32)."""
+    import numpy as np
+    offs, pos = [], 0
+    for p in payloads:
+        offs.append(pos)
+        pos += (len(p) + 3) // 4 * 4 + 4
+    buf = np.zeros(max(pos, 4), dtype=np.uint8)
+    for o, p in zip(offs, payloads):
+        buf[o:o + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    return (torch.from_numpy(buf).to(device), torch.tensor(offs, dtype=torch.int64, device=device),
+            torch.tensor([len(p) for p in payloads], dtype=torch.int32, device=device))
+
+
+def ac_decode(cdf, payload_buf, offsets, nbytes, n_streams, n_sym, monotone, broadcast_row=False):
+    """-> sym int16 (n_streams, n_sym) on the device."""
+    Lp = cdf.shape[-1]
+    sym = torch.empty(n_streams, n_sym, dtype=torch.int16, device=payload_buf.device)
+    call('l3c_ac_decode', ptr(cdf), 0 if broadcast_row else Lp, Lp, ptr(payload_buf, torch.uint8),
+         ptr(offsets, torch.int64), ptr(nbytes, torch.int32), n_streams, n_sym, int(bool(monotone)), ptr(sym), stream())
+    return sym
+
+
+def table_is_monotone(cdf):
+    """Host-synchronising check (used by the generic torchac.decode_cdf path on user tables)."""
+    Lp = cdf.shape[-1]
+    flag = torch.zeros(1, dtype=torch.int32, device=cdf.device)
+    call('l3c_cdf_check_monotone', ptr(cdf), cdf.numel() // Lp, Lp, ptr(flag), stream())
+    return int(flag.item()) == 0

@@ -25,9 +25,15 @@ def renorm_cast(cdf_float, precision=16):
     return cdf
 
 
-def mixture_cdf_table(pi, targets, mu, log_sigma):
-    """-> (N,H,W,Lp) int16, the table the reference feeds its coder.   torchac.py:174-178"""
-    return renorm_cast(mixture_cdf_float(pi, targets, mu, log_sigma))
+def mixture_cdf_table(pi, targets, mu, log_sigma, max_elems=1 << 27):
+    """-> (N,H,W,Lp) int16, the table the reference feeds its coder.   torchac.py:174-178
+    Built in row blocks so that the N*K*H*W*Lp intermediate stays below `max_elems` floats (the reference allocates it
+    whole: 4 GB for a 768x512 RGB channel); every op is elementwise in H, so the result is identical."""
+    N, K, H, W = pi.shape
+    rows = max(1, min(H, max_elems // max(1, N * K * W * targets.shape[0])))
+    parts = [renorm_cast(mixture_cdf_float(pi[:, :, r:r + rows], targets, mu[:, :, r:r + rows], log_sigma[:, :, r:r + rows]))
+             for r in range(0, H, rows)]
+    return parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
 
 
 def uniform_cdf_table(H, W, L):

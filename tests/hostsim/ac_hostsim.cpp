@@ -1,0 +1,76 @@
+// tests/hostsim/ac_hostsim.cpp -- TEST INFRASTRUCTURE: runs the product's coder state machine
+// (l3c-pytorch_amd/csrc/ac_core.h, the code the HIP kernels instantiate per lane / per wavefront) on the host CPU so
+// that its integer logic can be checked against the reference KATs without a GPU.  Not part of the product path.
+//
+// Build: g++ -O2 -shared -fPIC -I l3c-pytorch_amd/csrc -o tests/hostsim/_build/libac_hostsim.so tests/hostsim/ac_hostsim.cpp
+#include <cstring>
+#include <vector>
+
+#include "ac_core.h"
+
+namespace {
+struct VecStore {
+    uint32_t *words;
+    void operator()(uint32_t i, uint32_t w) const { words[i] = w; }
+};
+struct MemFetch {
+    const uint8_t *p;
+    uint32_t nbytes;
+    uint32_t operator()(uint32_t i) const {
+        uint32_t w = 0;
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t off = (uint64_t)i * 4 + k;
+            w = (w << 8) | (off < nbytes ? p[off] : 0u);
+        }
+        return w;
+    }
+};
+}  // namespace
+
+extern "C" {
+
+// words of the interval stream in the layout of include/l3c_hip.h for ONE stream (n_streams == 1)
+long long hostsim_encode(const uint16_t *cdf, long long row_stride, int Lp, const int16_t *sym, long long N,
+                         uint8_t *out, long long cap) {
+    std::vector<uint32_t> words((size_t)(N / 2 + 16));
+    l3c::WordSink<VecStore> sink(VecStore{words.data()});
+    uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+    for (long long i = 0; i < N; ++i) {
+        const uint16_t *row = cdf + i * row_stride;
+        const int x = sym[i];
+        const uint32_t c_lo = row[x];
+        const uint32_t c_hi = x == Lp - 2 ? 0x10000u : row[x + 1];
+        const uint32_t w = l3c::pack_interval(c_lo, c_hi);
+        l3c::encode_symbol(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
+    }
+    l3c::encode_finish(low, pending, sink);
+    const uint32_t n = sink.finish();
+    if ((long long)n <= cap) std::memcpy(out, words.data(), n);
+    return n;
+}
+
+void hostsim_decode(const uint16_t *cdf, long long row_stride, int Lp, const uint8_t *in, long long in_len,
+                    int monotone, int16_t *sym_out, long long N) {
+    l3c::WordSource<MemFetch> src(MemFetch{in, (uint32_t)in_len});
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint32_t value = src.take(32);
+    const uint32_t top = (uint32_t)(Lp - 2);
+    for (long long i = 0; i < N; ++i) {
+        const uint16_t *row = cdf + i * row_stride;
+        const uint32_t count = l3c::decode_count(low, high, value);
+        uint32_t x;
+        if (monotone) {  // what the wavefront does: rank of `count` among the valid entries (ballot + popcount)
+            uint32_t rank = 0;
+            for (uint32_t m = 0; m <= top; ++m) rank += row[m] <= count;
+            x = rank ? rank - 1 : 0;
+        } else {
+            x = l3c::ref_binsearch([&](uint32_t m) { return (uint32_t)row[m]; }, count, top);
+        }
+        sym_out[i] = (int16_t)x;
+        if (i == N - 1) break;
+        const uint32_t c_lo = row[x];
+        const uint32_t c_hi = x == top ? 0x10000u : row[x + 1];
+        l3c::decode_advance(low, high, value, c_lo, c_hi, src);
+    }
+}
+}

@@ -1,0 +1,96 @@
+"""-m gpu: the HIP range coder (csrc/ac_kernels.hip) against the reference KATs and the oracle, through the C ABI.
+Integer work: everything here is bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ac as oracle_ac  # noqa: E402
+
+
+def _names(g):
+    return sorted({k.split('/')[0] for k in g.files if k.endswith('/sym')})
+
+
+def test_encode_decode_reference_kats(golden):
+    from tests import gpu_util as gu
+    g = golden('ac_kat.npz')
+    for name in _names(g):
+        tab, sym, ref = g[name + '/cdf'], g[name + '/sym'], g[name + '/bytes'].tobytes()
+        got = gu.hip_encode_streams(tab[None], sym[None])[0]
+        assert got == ref, (name, len(got), len(ref))
+        for monotone in (True, False):
+            dec = gu.hip_decode_streams(tab[None], [ref], monotone)[0]
+            assert (dec == sym).all(), (name, monotone, int((dec != sym).sum()))
+
+
+def test_decode_truncated_stream_like_reference(golden):
+    from tests import gpu_util as gu
+    g = golden('ac_kat.npz')
+    dec = gu.hip_decode_streams(g['truncated/cdf'][None], [g['truncated/bytes'].tobytes()], False)[0]
+    assert (dec == g['truncated/decoded']).all()
+
+
+@pytest.mark.parametrize('S,N,Lp', [(1, 1, 257), (3, 65, 26), (70, 1000, 257), (130, 517, 26), (64, 64, 3), (5, 4097, 257)])
+def test_many_streams_vs_oracle(S, N, Lp):
+    """streams per lane (encode) / per wavefront (decode); S crosses the 64-lane boundary, N the 64-symbol blocks."""
+    from tests import gpu_util as gu
+    rng = np.random.RandomState(S * 1000 + N)
+    tabs = gu.random_tables(rng, S, N, Lp, shape=rng.choice([0.05, 0.3, 2.0]))
+    syms = gu.sample_symbols(rng, tabs)
+    syms[::2] = rng.randint(0, Lp - 1, size=syms[::2].shape)       # unlikely symbols too
+    got = gu.hip_encode_streams(tabs, syms)
+    for s in range(S):
+        assert got[s] == oracle_ac.encode(tabs[s], syms[s]), s
+    for monotone in (True, False):
+        dec = gu.hip_decode_streams(tabs, got, monotone)
+        assert (dec == syms).all(), monotone
+
+
+def test_uniform_row_broadcast():
+    from l3c_pytorch_amd import ops
+    from l3c_pytorch_amd.bitcoding.bitcoding import uniform_cdf_row
+    rng = np.random.RandomState(3)
+    row = uniform_cdf_row(25)
+    S, N = 10, 6144
+    sym = rng.randint(0, 25, size=(S, N)).astype(np.int16)
+    iv = ops.intervals_from_table(row.cuda(), torch.from_numpy(sym).cuda(), S, N, broadcast_row=True)
+    out, n = ops.ac_encode(iv, S, N)
+    n, out = n.cpu().numpy(), out.cpu().numpy()
+    payloads = [out[i, :n[i]].tobytes() for i in range(S)]
+    for s in range(S):
+        assert payloads[s] == oracle_ac.encode(row.numpy(), sym[s]), s
+    buf, offs, lens = ops.pack_streams(payloads)
+    dec = ops.ac_decode(row.cuda(), buf, offs, lens, S, N, True, broadcast_row=True).cpu().numpy()
+    assert (dec == sym).all()
+
+
+def test_monotone_check_kernel():
+    from l3c_pytorch_amd import ops
+    from tests import gpu_util as gu
+    rng = np.random.RandomState(5)
+    tab = gu.random_tables(rng, 1, 200, 257)[0]
+    t = torch.from_numpy(tab.view(np.int16)).cuda()
+    assert ops.table_is_monotone(t)
+    tab[100, -1] = 0                       # the wrapped last entry is outside [0, Lp-2]: still fine
+    assert ops.table_is_monotone(torch.from_numpy(tab.view(np.int16)).cuda())
+    tab[150, 7] = tab[150, 6]
+    assert not ops.table_is_monotone(torch.from_numpy(tab.view(np.int16)).cuda())
+
+
+def test_torchac_facade_roundtrip_and_errors(golden):
+    """reference API (torchac.py:87-166) with host tensors, as coders.py calls it."""
+    from l3c_pytorch_amd import torchac
+    g = golden('ac_kat.npz')
+    tab, sym, ref = g['random_Lp26/cdf'], g['random_Lp26/sym'], g['random_Lp26/bytes'].tobytes()
+    cdf = torch.from_numpy(tab.view(np.int16).copy()).reshape(1, 1, -1, 26)
+    assert torchac.encode_cdf(cdf, torch.from_numpy(sym)) == ref
+    dec = torchac.decode_cdf(cdf, ref)
+    assert dec.dtype == torch.int16 and not dec.is_cuda and (dec.numpy() == sym).all()
+    with pytest.raises(RuntimeError):
+        torchac.encode_cdf(cdf.reshape(-1, 26), torch.from_numpy(sym))
+    with pytest.raises(ValueError):
+        torchac.encode_logistic_mixture(torch.zeros(26).cuda(), torch.zeros(1, 10, 4, 4), torch.zeros(1, 10, 4, 4),
+                                        torch.zeros(1, 10, 4, 4), torch.zeros(16, dtype=torch.int16))
+    assert torchac.CUDA_SUPPORTED and not torchac.CPU_SUPPORTED

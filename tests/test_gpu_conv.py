@@ -1,0 +1,144 @@
+"""-m gpu: the conv stack kernels (csrc/conv_mfma.hip, csrc/conv_small.hip) against a plain torch fp32 reference of
+the same op (F.conv2d on the CPU) and against the VALU cross-check kernel.  Floating point: tolerance stated per test."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_conv(x_nchw, w, b, stride, dil):
+    k = w.shape[-1]
+    pad = k // 2 if dil == 1 else dil
+    return F.conv2d(x_nchw, w, b, stride=stride, dilation=dil, padding=pad)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+CASES = [
+    # KS, stride, dil, Cin, Cout, B, H, W
+    (3, 1, 1, 64, 64, 1, 8, 32),          # exactly one tile
+    (3, 1, 1, 64, 64, 2, 13, 45),         # ragged tiles, batch
+    (3, 1, 2, 64, 64, 1, 19, 37),
+    (3, 1, 4, 64, 64, 1, 21, 50),
+    (5, 2, 1, 64, 64, 2, 22, 70),         # 5x5 stride 2 (even/odd column split in LDS)
+    (5, 2, 1, 64, 64, 1, 9, 7),
+    (1, 1, 1, 192, 120, 1, 11, 33),       # 1x1, Cin 192, Cout not a multiple of 64
+    (1, 1, 1, 192, 150, 2, 5, 70),
+    (3, 1, 1, 64, 256, 1, 10, 34),        # tail conv: 4 output-channel chunks
+    (3, 1, 1, 64, 64, 1, 1, 1),           # degenerate image
+    (3, 1, 1, 64, 64, 1, 4, 6),
+]
+
+
+@pytest.mark.parametrize('KS,stride,dil,Cin,Cout,B,H,W', CASES)
+def test_conv_mfma_vs_torch(KS, stride, dil, Cin, Cout, B, H, W):
+    """fp32 MFMA is an exact fma chain; only the summation order differs from the CPU conv -> tolerance
+    1e-5 * sqrt(K) * max|term| ~ a few 1e-5 abs for unit-scale data (K = KS*KS*Cin <= 1600)."""
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(KS * 1000 + H * 10 + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, KS, KS, generator=g) / np.sqrt(Cin * KS * KS)
+    b = torch.randn(Cout, generator=g)
+    ref = _ref_conv(x, w, b, stride, dil)
+    layer = ops.PackedConv(w, b, stride=stride, dilation=dil)
+    got = ops.conv(_nhwc(x).cuda(), layer, impl='mfma').cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err < 3e-5, err
+    direct = ops.conv(_nhwc(x).cuda(), layer, impl='direct').cpu().permute(0, 3, 1, 2)
+    assert (direct - ref).abs().max().item() < 3e-5
+    # determinism: same launch twice is bit-identical; a batch of two equals two single launches
+    again = ops.conv(_nhwc(x).cuda(), layer, impl='mfma').cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, again)
+    if B > 1:
+        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, impl='mfma').cpu().permute(0, 3, 1, 2)
+        assert torch.equal(single, got[1:2])
+
+
+def test_conv_epilogues():
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(1)
+    B, H, W = 2, 12, 40
+    x = torch.randn(B, 64, H, W, generator=g)
+    res = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g)
+    layer = ops.PackedConv(w, b)
+    xd, rd = _nhwc(x).cuda(), _nhwc(res).cuda()
+    ref = _ref_conv(x, w, b, 1, 1)
+    got = ops.conv(xd, layer, relu=True).cpu().permute(0, 3, 1, 2)
+    assert (got - F.relu(ref)).abs().max() < 3e-5
+    got = ops.conv(xd, layer, residual=rd).cpu().permute(0, 3, 1, 2)
+    assert (got - (ref + res)).abs().max() < 3e-5
+    # channel-slice output (the atrous branches write into the 192-wide concat buffer)
+    cat = torch.zeros(B, H, W, 192, device='cuda')
+    ops.conv(xd, layer, out=cat, out_coff=64)
+    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2) - ref).abs().max() < 3e-5
+    assert float(cat[..., :64].abs().max()) == 0 and float(cat[..., 128:].abs().max()) == 0
+    # pixel shuffle epilogue == nn.PixelShuffle(2) of the 256-channel conv (edsr.py:98-99)
+    w4 = torch.randn(256, 64, 3, 3, generator=g) / 24
+    b4 = torch.randn(256, generator=g)
+    up = ops.conv(xd, ops.PackedConv(w4, b4), pixel_shuffle=True).cpu().permute(0, 3, 1, 2)
+    ref_up = F.pixel_shuffle(_ref_conv(x, w4, b4, 1, 1), 2)
+    assert up.shape == ref_up.shape and (up - ref_up).abs().max() < 3e-5
+
+
+def test_rgb_head_vs_torch(synthetic_l3c):
+    from l3c_pytorch_amd import ops
+    cfg, sd = synthetic_l3c
+    g = torch.Generator().manual_seed(2)
+    img = torch.randint(0, 256, (2, 3, 21, 45), generator=g).float()
+    x = F.conv2d(img, sd['sub_rgb_mean.weight'], sd['sub_rgb_mean.bias'])
+    x = F.conv2d(x, sd['heads.0.head.0.weight'], sd['heads.0.head.0.bias'])
+    ref = F.conv2d(x, sd['heads.0.head.1.head.weight'], sd['heads.0.head.1.head.bias'], padding=1)
+    d = lambda t: t.cuda().contiguous()   # noqa: E731
+    out, shifted = ops.rgb_head(d(img), d(sd['sub_rgb_mean.weight'].reshape(3, 3)), d(sd['sub_rgb_mean.bias']),
+                                d(sd['heads.0.head.0.weight'].reshape(3, 3)), d(sd['heads.0.head.0.bias']),
+                                d(sd['heads.0.head.1.head.weight']), d(sd['heads.0.head.1.head.bias']), want_shifted=True)
+    assert (shifted.cpu() - x).abs().max() < 1e-5
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max() < 1e-5
+
+
+def test_to_q_quantize_and_dec_head_vs_torch(synthetic_l3c):
+    from l3c_pytorch_amd import ops
+    from oracle import net as onet
+    cfg, sd = synthetic_l3c
+    g = torch.Generator().manual_seed(3)
+    feat = torch.randn(2, 64, 9, 14, generator=g) * 3
+    w, b, levels = sd['nets.0.enc.to_q.0.weight'], sd['nets.0.enc.to_q.0.bias'], sd['nets.0.enc.levels']
+    bn_ref = F.conv2d(feat, w, b)
+    sym, bn_q, bn = ops.to_q_quantize(_nhwc(feat).cuda(), w.reshape(5, 64).cuda().contiguous(), b.cuda(), levels.cuda(),
+                                      want_bn=True)
+    assert (bn.cpu() - bn_ref).abs().max() < 1e-5
+    # quantise the kernel's OWN pre-quantisation values with the oracle: must agree exactly (argmin, first-min ties)
+    bq_ref, sym_ref = onet.quantise(bn.cpu(), levels)
+    assert torch.equal(sym.cpu().long(), sym_ref) and torch.equal(bn_q.cpu(), bq_ref)
+    # exact ties between two levels resolve to the lower index like torch.min
+    tie = torch.zeros(1, 64, 1, 2)
+    wz = torch.zeros(5, 64)
+    bz = torch.tensor([(levels[3] + levels[4]) / 2] * 5)
+    s2, _ = ops.to_q_quantize(_nhwc(tie).cuda(), wz.cuda(), bz.cuda(), levels.cuda())
+    _, s2_ref = onet.quantise(bz.reshape(1, 5, 1, 1).expand(1, 5, 1, 2).contiguous(), levels)
+    assert torch.equal(s2.cpu().long(), s2_ref)
+    # decoder head
+    wh, bh = sd['nets.0.dec.head.weight'], sd['nets.0.dec.head.bias']
+    fuse = torch.randn(2, 64, 9, 14, generator=g)
+    ref = F.conv2d(bq_ref, wh, bh) + fuse
+    got = ops.dec_head(bn_q, wh.reshape(64, 5).cuda().contiguous(), bh.cuda(), _nhwc(fuse).cuda())
+    assert (got.cpu().permute(0, 3, 1, 2) - ref).abs().max() < 1e-5
+    got = ops.dec_head(bn_q, wh.reshape(64, 5).cuda().contiguous(), bh.cuda(), None)
+    assert (got.cpu().permute(0, 3, 1, 2) - F.conv2d(bq_ref, wh, bh)).abs().max() < 1e-5
+
+
+def test_sym_to_bn_bit_exact():
+    from l3c_pytorch_amd import ops
+    from l3c_pytorch_amd.modules import quantizer
+    sym = torch.arange(25, dtype=torch.int16)
+    got = ops.sym_to_bn(sym.cuda(), 2 / 24, -1).cpu()
+    assert torch.equal(got, quantizer.to_bn(sym, -1, 1, 25))
+    sym = torch.arange(256, dtype=torch.int16)
+    assert torch.equal(ops.sym_to_bn(sym.cuda(), 1.0, 0).cpu(), sym.float())

@@ -1,0 +1,161 @@
+"""-m gpu: MultiscaleNetwork / MultiscaleBlueprint / Bitcoding on the MI355X path against the reference fixture (config[0])
+and the oracle at other sizes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import bitcoding as obc, net as onet  # noqa: E402
+
+
+@pytest.fixture(scope='module')
+def blueprint(synthetic_l3c):
+    from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
+    cfg, sd = synthetic_l3c
+    bp = MultiscaleBlueprint(cfg)
+    bp.net.load_state_dict(sd, strict=True)
+    bp.set_eval()
+    return bp
+
+
+def _near_tie(x_prequant, levels, tol=5e-5):
+    d = np.sort(np.abs(x_prequant[..., None] - levels), axis=-1)
+    return (d[..., 1] - d[..., 0]) < tol
+
+
+def test_forward_matches_reference_fixture(golden, blueprint, synthetic_l3c):
+    """config[0] (32x32): P and features within 1e-5-class fp32 tolerance of the reference CPU forward (abs 5e-5 on values
+    of magnitude ~1..30 after ~40 conv layers with a different summation order); symbols identical except provable
+    quantiser near-ties; per-scale bpsp within 1e-4 relative."""
+    cfg, sd = synthetic_l3c
+    g = golden('net_32.npz')
+    img = torch.from_numpy(g['img'].astype(np.float32)).cuda()
+    out = blueprint.forward(img)
+    levels = sd['nets.0.enc.levels'].numpy()
+    assert torch.equal(out.S[0].cpu(), torch.from_numpy(g['S0'].astype(np.int64)))
+    flips = 0
+    for s in range(3):
+        bad = out.S[s + 1].cpu().numpy() != g['S%d' % (s + 1)]
+        flips += int(bad.sum())
+        assert bad.sum() == 0 or _near_tie(g['enc_bn%d' % s], levels)[bad].all(), s
+        Fe = out.raw.F_enc[s].cpu().permute(0, 3, 1, 2).numpy()
+        assert np.abs(Fe - g['enc_F%d' % s]).max() < 5e-5, (s, np.abs(Fe - g['enc_F%d' % s]).max())
+    if flips == 0:
+        for s in range(3):
+            P = out.P[s].cpu().numpy()
+            assert P.shape == g['P%d' % s].shape
+            err = np.abs(P - g['P%d' % s]).max()
+            assert err < 1e-4, (s, err)
+        loss = blueprint.get_loss(out)
+        got = np.array([float(b) for b in loss.nonrecursive_bpsps])
+        assert np.allclose(got, g['bpsp'], rtol=1e-4), (got, g['bpsp'])
+    assert out.L == [256, 25, 25, 25] and out.bn[0] is None
+    for s in range(1, 4):
+        assert torch.equal(out.bn[s].cpu(), torch.from_numpy(levels)[out.S[s].cpu()])
+
+
+def test_decoder_side_on_reference_bottlenecks(golden, blueprint):
+    """get_P fed with the REFERENCE's bn_q (so no quantiser flip can leak in): F and P within fp32 tolerance."""
+    g = golden('net_32.npz')
+    f_prev = None
+    for s in (2, 1, 0):
+        bn = torch.from_numpy(g['bn%d' % (s + 1)]).cuda()
+        P, f_prev = blueprint.net.get_P(s, bn, f_prev)
+        assert np.abs(f_prev.cpu().numpy() - g['dec_F%d' % s]).max() < 5e-5, s
+        assert np.abs(P.cpu().numpy() - g['P%d' % s]).max() < 1e-4, s
+
+
+@pytest.mark.parametrize('H,W', [(40, 56), (64, 96), (8, 8)])
+def test_forward_vs_oracle_other_sizes(blueprint, synthetic_l3c, H, W):
+    from l3c_pytorch_amd.helpers import synthetic
+    cfg, sd = synthetic_l3c
+    img = synthetic.make_image(H, W, 5, 'natural').unsqueeze(0).float()
+    with torch.no_grad():
+        ref = onet.forward(img, sd)
+    out = blueprint.forward(img.cuda())
+    levels = sd['nets.0.enc.levels'].numpy()
+    for s in range(3):
+        bad = (out.S[s + 1].cpu() != ref.S[s + 1]).numpy()
+        if bad.any():
+            pytest.skip('quantiser near-tie flipped a symbol at this size; downstream tensors are not comparable')
+        assert (out.raw.F_enc[s].cpu().permute(0, 3, 1, 2) - ref.F_enc[s]).abs().max() < 5e-5
+    for s in range(3):
+        assert (out.P[s].cpu() - ref.P[s]).abs().max() < 1e-4, s
+
+
+def test_get_P_is_bit_identical_to_forward_and_batch_invariant(blueprint):
+    """The lossless contract (P4): the decoder recomputes P from bn_q with the same kernels and tile schedule."""
+    from l3c_pytorch_amd.helpers import synthetic
+    imgs = torch.stack([synthetic.make_image(48, 72, i, 'natural') for i in range(3)]).float().cuda()
+    out = blueprint.forward(imgs)
+    f_prev = None
+    for s in (2, 1, 0):
+        P, f_prev = blueprint.net.get_P(s, out.bn[s + 1], f_prev)
+        assert torch.equal(P, out.P[s]), s
+    single = blueprint.forward(imgs[1:2])
+    for s in range(3):
+        assert torch.equal(single.P[s], out.P[s][1:2]), s
+        assert torch.equal(single.S[s + 1], out.S[s + 1][1:2])
+
+
+@pytest.mark.parametrize('H,W,B,kind', [(32, 32, 1, 'uniform'), (64, 96, 3, 'natural'), (8, 16, 2, 'smooth'),
+                                        (128, 192, 2, 'natural')])
+def test_encode_decode_lossless(blueprint, H, W, B, kind):
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.helpers import synthetic
+    imgs = torch.stack([synthetic.make_image(H, W, 10 + i, kind) for i in range(B)]).long()
+    bc = Bitcoding(blueprint)
+    enc = bc.encode_batch(imgs)
+    files = enc.to_bytes()
+    sizes = enc.file_sizes().cpu().tolist()
+    assert sizes == [len(f) for f in files]
+    dec, pads = bc.decode_batch(files)
+    assert torch.equal(dec.cpu(), imgs)
+    # a batch codes every image exactly like a batch of one
+    alone = bc.encode_batch(imgs[:1]).to_bytes()[0]
+    assert alone == files[0]
+    # fixed framing overhead: 116 bytes
+    n_payload = int(enc.total_payload_bytes()[0])
+    assert len(files[0]) - n_payload == 116
+
+
+def test_file_api_with_padding_and_reference_file_size(golden, blueprint, tmp_path):
+    """reference API: encode(img, path) -> bpsp, decode(path) -> 1CHW long; odd sizes are centre padded."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.helpers import synthetic
+    bc = Bitcoding(blueprint, compare_with_theory=True)
+    g = golden('net_32.npz')
+    img = torch.from_numpy(g['img'].astype(np.int64))
+    p = str(tmp_path / 'a.l3c')
+    bpsp = bc.encode(img, p)
+    size = os.path.getsize(p)
+    assert abs(bpsp - size * 8 / img.numel()) < 1e-9
+    # same weights, same image: the reference's file is 7111 bytes; ours differs only where a CDF rounding moved
+    assert abs(size - len(g['l3c'])) <= 16, (size, len(g['l3c']))
+    assert torch.equal(bc.decode(p).cpu(), img)
+    odd = synthetic.make_image(37, 51, 4, 'natural').unsqueeze(0).long()
+    p2 = str(tmp_path / 'b.l3c')
+    bc.encode(odd, p2)
+    back = bc.decode(p2)
+    assert back.shape == odd.shape and torch.equal(back.cpu(), odd)
+    with open(p2, 'rb') as f:
+        import struct
+        assert struct.unpack('<4H', f.read(8)) == (2, 3, 1, 2)      # left, right, top, bottom for 37x51 -> 40x56
+
+
+def test_auto_crop_parts(blueprint, tmp_path, monkeypatch):
+    from l3c_pytorch_amd import auto_crop
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.helpers import synthetic
+    monkeypatch.setattr(auto_crop, '_NEEDS_CROP_DIM', 40 * 40)
+    img = synthetic.make_image(64, 80, 8, 'natural').unsqueeze(0).long()
+    bc = Bitcoding(blueprint)
+    p = str(tmp_path / 'big.l3c')
+    bpsp = bc.encode(img, p)
+    parts = sorted(os.listdir(str(tmp_path)))
+    assert parts == ['big.l3c.part0', 'big.l3c.part1', 'big.l3c.part2', 'big.l3c.part3']
+    back = bc.decode(p + '.part2')
+    assert torch.equal(back.cpu(), img) and bpsp > 0
