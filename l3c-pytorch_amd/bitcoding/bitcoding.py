@@ -62,9 +62,17 @@ class EncodedBatch(object):
         self.B = B
         self.padded_shape = padded_shape     # (H, W) of the padded images
         self.scales = []                     # (C, H, W, out uint8 (B*C, stride), nbytes int32 (B*C,))
+        self.done = []                       # events on the coder streams; wait() orders the current stream after them
+
+    def wait(self):
+        """Make the current stream wait for the range-coder launches (they run on side streams)."""
+        for ev in self.done:
+            torch.cuda.current_stream().wait_event(ev)
+        return self
 
     def total_payload_bytes(self):
         """int64 device tensor (B,): entropy-coded bytes per image (no host sync)."""
+        self.wait()
         tot = None
         for C, H, W, out, nbytes in self.scales:
             t = nbytes.to(torch.int64).reshape(self.B, C).sum(dim=1)
@@ -78,6 +86,7 @@ class EncodedBatch(object):
 
     def payloads(self):
         """list over scales (coarse -> fine) of [B][C] bytes objects (one D2H copy per scale)."""
+        self.wait()
         res = []
         for C, H, W, out, nbytes in self.scales:
             n = nbytes.cpu().numpy()
@@ -107,6 +116,14 @@ class Bitcoding(object):
         self.compare_with_theory = compare_with_theory
         self.times = times if times is not None else _NullTimes()
         self._const = {}
+        self._coder_streams = None
+
+    def _streams(self, n):
+        """Side streams for the range coder: its launches are a handful of long-running wavefronts (one lane per
+        stream), so they are overlapped with whatever the main stream does next (the next batch's convolutions)."""
+        if self._coder_streams is None or len(self._coder_streams) < n:
+            self._coder_streams = [torch.cuda.Stream() for _ in range(n)]
+        return self._coder_streams
 
     # ---- constants --------------------------------------------------------------------------------------------------
 
@@ -143,7 +160,9 @@ class Bitcoding(object):
         raw = out.raw
         K = net.config_ms.prob.K
         enc = EncodedBatch(B, (H, W))
-        for scale, dmll, uniform in self.iter_scale_dmll():
+        main = torch.cuda.current_stream()
+        side = self._streams(net.scales + 1)
+        for i, (scale, dmll, uniform) in enumerate(self.iter_scale_dmll()):
             sym = raw.sym[scale]
             _, C, Hs, Ws = sym.shape
             if uniform:
@@ -151,8 +170,16 @@ class Bitcoding(object):
                                               broadcast_row=True)
             else:
                 iv = ops.dmll_encode_intervals(raw.P[scale], sym, self._targets(dmll), C, K, dmll.rgb_scale)
-            stream_bytes, nbytes = ops.ac_encode(iv, B * C, Hs * Ws)
+            ready = torch.cuda.Event()
+            ready.record(main)
+            with torch.cuda.stream(side[i]):
+                side[i].wait_event(ready)
+                iv.record_stream(side[i])
+                stream_bytes, nbytes = ops.ac_encode(iv, B * C, Hs * Ws)
+                done = torch.cuda.Event()
+                done.record(side[i])
             enc.scales.append((C, Hs, Ws, stream_bytes, nbytes))
+            enc.done.append(done)
         return enc
 
     def decode_batch(self, files):

@@ -228,5 +228,41 @@ struct WordSource {
     }
 };
 
+
+// ---- encoder fast path ------------------------------------------------------------------------------------------------
+// encode_symbol() above is the literal statement (a put per run).  The kernel's inner loop uses this variant: when the
+// bits a symbol emits -- first bit, `pending` complements, n-1 further bits -- fit one 32-bit word (practically always:
+// it takes >= 32 pending underflow bits or a 32-bit common prefix to exceed it) they are composed into ONE value and
+// appended with ONE put; anything longer falls back to the literal path.  Bit-identical by construction; the host sim
+// runs the KATs through it.
+template <class Sink>
+L3C_HD void encode_emit_long(Sink &sink, uint32_t low, int n, uint32_t &pending) {
+    put_with_pending(sink, low >> 31, pending);
+    if (n > 1) sink.put((low << 1) >> (33 - n), n - 1);
+}
+
+template <class Sink>
+L3C_HD void encode_symbol_fast(uint32_t &low, uint32_t &high, uint32_t &pending, uint32_t c_lo, uint32_t c_hi, Sink &sink) {
+    interval_update(low, high, c_lo, c_hi);
+    int n, m;
+    uint32_t nl, nh;
+    renorm_counts(low, high, n, m, nl, nh);
+    const uint32_t total = n ? (uint32_t)n + pending : 0u;
+    if (__builtin_expect(total > 32u, 0)) {
+        encode_emit_long(sink, low, n, pending);
+        pending = (uint32_t)m;
+    } else {
+        const uint32_t first = low >> 31;
+        const uint32_t head = (first << pending) | (first ? 0u : ones((int)pending));   // 1 + pending bits
+        const int nn = n ? n - 1 : 0;
+        const uint32_t rest = (low & 0x7FFFFFFFu) >> ((32 - n) & 31);                      // n - 1 bits (n >= 1)
+        const uint32_t v = n ? ((head << nn) | rest) : 0u;
+        sink.put(v, (int)total);
+        pending = n ? (uint32_t)m : pending + (uint32_t)m;
+    }
+    low = nl;
+    high = nh;
+}
+
 }  // namespace l3c
 #endif

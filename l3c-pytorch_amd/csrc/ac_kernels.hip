@@ -65,24 +65,33 @@ __global__ __launch_bounds__(64) void ac_encode_kernel(const uint32_t *__restric
 #pragma unroll
         for (int k = 0; k < 4; ++k) cur[k] = p[k];
     }
-    for (int64_t g = 0; g < n_groups; ++g) {
+    const int64_t full_groups = n_sym / 16;
+    for (int64_t g = 0; g < full_groups; ++g) {
         if (g + 1 < n_groups) {
             const uint4 *p = group_ptr(g + 1);
 #pragma unroll
             for (int k = 0; k < 4; ++k) nxt[k] = p[k];
         }
-        const int valid = (int)((n_sym - g * 16) < 16 ? (n_sym - g * 16) : 16);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k * 4 + j < valid)
-                    l3c::encode_symbol(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
-            }
+            for (int j = 0; j < 4; ++j)
+                l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
+    }
+    if (full_groups < n_groups) {   // ragged tail (< 16 symbols), already in `cur`
+        const int valid = (int)(n_sym - full_groups * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k * 4 + j < valid)
+                    l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
+        }
     }
     l3c::encode_finish(low, pending, sink);
     const uint32_t nbytes = sink.finish();

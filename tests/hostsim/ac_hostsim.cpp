@@ -31,7 +31,7 @@ extern "C" {
 
 // words of the interval stream in the layout of include/l3c_hip.h for ONE stream (n_streams == 1)
 long long hostsim_encode(const uint16_t *cdf, long long row_stride, int Lp, const int16_t *sym, long long N,
-                         uint8_t *out, long long cap) {
+                         uint8_t *out, long long cap, int fast) {
     std::vector<uint32_t> words((size_t)(N / 2 + 16));
     l3c::WordSink<VecStore> sink(VecStore{words.data()});
     uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
@@ -41,7 +41,8 @@ long long hostsim_encode(const uint16_t *cdf, long long row_stride, int Lp, cons
         const uint32_t c_lo = row[x];
         const uint32_t c_hi = x == Lp - 2 ? 0x10000u : row[x + 1];
         const uint32_t w = l3c::pack_interval(c_lo, c_hi);
-        l3c::encode_symbol(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
+        if (fast) l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
+        else l3c::encode_symbol(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
     }
     l3c::encode_finish(low, pending, sink);
     const uint32_t n = sink.finish();

@@ -23,7 +23,7 @@ def _get():
         lib = ctypes.CDLL(_SO)
         lib.hostsim_encode.restype = ctypes.c_longlong
         lib.hostsim_encode.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p,
-                                       ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong]
+                                       ctypes.c_longlong, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
         lib.hostsim_decode.restype = None
         lib.hostsim_decode.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
@@ -31,12 +31,12 @@ def _get():
     return _lib
 
 
-def encode(tab, sym):
+def encode(tab, sym, fast=True):
     tab = np.ascontiguousarray(tab).view(np.uint16)
     sym = np.ascontiguousarray(sym, dtype=np.int16)
     out = np.zeros(2 * len(sym) + 64, np.uint8)
     n = _get().hostsim_encode(tab.ctypes.data, tab.shape[1], tab.shape[1], sym.ctypes.data, len(sym),
-                              out.ctypes.data, len(out))
+                              out.ctypes.data, len(out), int(fast))
     assert n <= len(out)
     return out[:n].tobytes()
 

@@ -14,7 +14,8 @@ def test_hostsim_kats(golden):
     g = golden('ac_kat.npz')
     for n in _names(g):
         tab, sym, ref = g[n + '/cdf'], g[n + '/sym'], g[n + '/bytes'].tobytes()
-        assert hs.encode(tab, sym) == ref, n
+        assert hs.encode(tab, sym, fast=True) == ref, n
+        assert hs.encode(tab, sym, fast=False) == ref, n
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), n
         assert (hs.decode(tab, ref, len(sym), False) == sym).all(), n
 
@@ -47,7 +48,8 @@ def test_hostsim_random_vs_oracle():
     for it in range(120):
         tab, sym = _random_case(rng, it)
         ref = ac.encode(tab, sym)
-        assert hs.encode(tab, sym) == ref, it
+        assert hs.encode(tab, sym, fast=True) == ref, it
+        assert hs.encode(tab, sym, fast=False) == ref, it
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), it
         assert (hs.decode(tab, ref, len(sym), False) == sym).all(), it
         junk = rng.randint(0, 256, size=rng.randint(0, 200)).astype(np.uint8).tobytes()
