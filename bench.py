@@ -38,13 +38,14 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=16, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    ap.add_argument('--coder-cus', type=int, default=0, help='compute units reserved for the range coder (0 = share all CUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events of the roofline leg')
     return ap.parse_args()
 
 
-def build_path(device):
+def build_path(device, coder_cus=0):
     import l3c_pytorch_amd  # noqa: F401
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
     from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
@@ -54,7 +55,7 @@ def build_path(device):
     bp = MultiscaleBlueprint(cfg)
     bp.net.load_state_dict(sd, strict=True)
     bp.set_eval()
-    return cfg, sd, bp, Bitcoding(bp), synthetic
+    return cfg, sd, bp, Bitcoding(bp, coder_cus=coder_cus), synthetic
 
 
 def cpu_baseline(sd, synthetic):
@@ -86,16 +87,20 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
 
-    cfg, sd, bp, bc, synthetic = build_path(device)
+    cfg, sd, bp, bc, synthetic = build_path(device, args.coder_cus)
     from l3c_pytorch_amd import _lib, ops
     B = args.batch
     # synthetic images (seed = global image index), resident in HBM before the timed region
     imgs = torch.stack([synthetic.make_image(H, W, rank * B + i, 'natural') for i in range(B)]).to(device)
     imgs_f = imgs.float().contiguous()
+    torch.cuda.synchronize()
+
+    compute_stream = bc.compute_stream if bc.compute_stream is not None else torch.cuda.current_stream()
 
     def step():
-        out = bp.net(imgs_f)
-        return bc.encode_batch(imgs_f, out=out)
+        with torch.cuda.stream(compute_stream):
+            out = bp.net(imgs_f)
+            return bc.encode_batch(imgs_f, out=out)
 
     def barrier():
         torch.cuda.synchronize()
@@ -123,7 +128,8 @@ def main():
     value = total_px / 1e6 / elapsed
 
     # bpsp of the coded batch (file bytes incl. framing) and lossless check of one image on rank 0
-    sizes = enc.file_sizes().cpu().numpy()
+    with torch.cuda.stream(compute_stream):
+        sizes = enc.file_sizes().cpu().numpy()
     bpsp = float(sizes.sum()) * 8 / (B * 3 * H * W)
 
     result = None
@@ -156,7 +162,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'L3C 0306_0001 (cr.cf, synthetic seeded checkpoint), batch of 768x512 synthetic RGB per '
                                    'GPU: net forward + fused logistic-mixture CDF head + HIP range coder -> bytes in HBM',
-                       'batch_per_gpu': B, 'image': '768x512', 'sharding': 'images, replicas only (no collective)'},
+                       'batch_per_gpu': B, 'image': '768x512', 'coder_cus': args.coder_cus, 'sharding': 'images, replicas only (no collective)'},
             'bpsp': round(bpsp, 4), 'flop_per_px': ALGO_FLOP_PER_PX,
             'end_to_end_tflops': round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / world, 2),
             'device': '{} ({}, {} CUs)'.format(name, arch, ncu),

@@ -41,6 +41,14 @@ const char *l3c_last_error(void);
 /* Name / CU count / gcnArchName of the current HIP device; fails when no GPU is visible (there is no CPU fallback). */
 int l3c_device_info(char *name_host, int name_cap, int *num_cu_host, char *arch_host, int arch_cap);
 
+/*
+ * A HIP stream whose kernels only run on compute units [first_cu, first_cu + n_cu) (hipExtStreamCreateWithCUMask).
+ * Used to give the latency-bound range-coder wavefronts CUs of their own while the MFMA-bound conv kernels of the next
+ * batch run on the complementary range: co-resident MFMA waves slow the coder's serial chain down 2.3x otherwise.
+ */
+int l3c_stream_create_cu_range(int first_cu, int n_cu, l3c_stream_t *stream_out_host);
+int l3c_stream_destroy(l3c_stream_t stream);
+
 /* ---- arithmetic coder (replaces torchac.cpp) ---------------------------------------------------------------------- */
 
 /*
@@ -62,15 +70,22 @@ int l3c_ac_intervals_from_table(const uint16_t *cdf, int64_t row_stride, int Lp,
                                 int64_t n_streams, int64_t n_sym, uint32_t *intervals, l3c_stream_t stream);
 
 /*
- * Range-encode n_streams independent symbol streams of equal length, one stream per lane (64 streams per wavefront).
- * Bit-exact restatement of encode() (torchac.cpp:152-227): 32-bit low/high, 16-bit precision, pending-bit carry
- * handling, final flush `pending+1` bits, zero padding to a byte boundary, MSB-first.
+ * Range-encode n_streams independent symbol streams of equal length.  Bit-exact restatement of encode()
+ * (torchac.cpp:152-227): 32-bit low/high, 16-bit precision, pending-bit carry handling, final flush of `pending+1`
+ * bits, zero padding to a byte boundary, MSB-first.  Two launches:
+ *   phase 1  one stream per lane (64 per wavefront): the serial interval recurrence only; every interval word is
+ *            REPLACED IN PLACE by a 28-bit record (top bits of low', prefix length n <= 18, underflow run m)
+ *   phase 2  one stream per wavefront, 64 symbols per step: records -> bits (wave scans + LDS merge), coalesced stores
+ * Precondition: c_high > c_low for every symbol (strictly increasing table rows), as for the reference.
+ *   intervals  in/out, CLOBBERED
  *   out        uint8 [n_streams][out_stride_bytes]; out_stride_bytes % 4 == 0 and >= l3c_ac_max_bytes(n_sym)
  *   out_nbytes uint32 [n_streams]   number of bytes produced per stream
+ *   workspace  l3c_ac_encode_workspace_bytes(n_streams) bytes, 4-byte aligned
  */
 int64_t l3c_ac_max_bytes(int64_t n_sym);
-int l3c_ac_encode(const uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t *out,
-                  int64_t out_stride_bytes, uint32_t *out_nbytes, l3c_stream_t stream);
+int64_t l3c_ac_encode_workspace_bytes(int64_t n_streams);
+int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride_bytes,
+                  uint32_t *out_nbytes, void *workspace, l3c_stream_t stream);
 
 /*
  * Range-decode n_streams streams, one wavefront per stream (the 64 lanes hold the CDF row of the current symbol and

@@ -36,10 +36,13 @@ PROTOTYPES = {
     'l3c_abi_version': (c_int, []),
     'l3c_last_error': (ctypes.c_char_p, []),
     'l3c_device_info': (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
+    'l3c_stream_create_cu_range': (c_int, [c_int, c_int, ctypes.POINTER(c_vp)]),
+    'l3c_stream_destroy': (c_int, [c_vp]),
     'l3c_interval_words': (c_i64, [c_i64, c_i64]),
     'l3c_ac_intervals_from_table': (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'l3c_ac_max_bytes': (c_i64, [c_i64]),
-    'l3c_ac_encode': (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp]),
+    'l3c_ac_encode_workspace_bytes': (c_i64, [c_i64]),
+    'l3c_ac_encode': (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     'l3c_cdf_check_monotone': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     'l3c_dmll_channel_params': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
@@ -105,6 +108,14 @@ def ptr(t, dtype=None):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def cu_range_stream(first_cu, n_cu):
+    """torch stream object whose kernels are confined to CUs [first_cu, first_cu + n_cu)."""
+    require_gpu()
+    h = c_vp()
+    call('l3c_stream_create_cu_range', first_cu, n_cu, ctypes.byref(h))
+    return torch.cuda.ExternalStream(h.value)
 
 
 def device_info():

@@ -264,5 +264,86 @@ L3C_HD void encode_symbol_fast(uint32_t &low, uint32_t &high, uint32_t &pending,
     high = nh;
 }
 
+
+// ---- encoder lean path -------------------------------------------------------------------------------------------------
+// Same bits as encode_symbol(), ~50 instructions and two rarely-taken branches per symbol (a lone wavefront retires about one
+// instruction per 2 ns on gfx950, so the instruction count IS the per-stream coding time):
+//   * E1/E2 and E3 shifts merged: with t = low' & ~high', the underflow run is the run of leading ones of t << (n+1), and
+//     low = (low' << (n+m)) & 0x7FFFFFFF, high = (high' << (n+m)) | ones(n+m) | 0x80000000 (the bits forced are already
+//     set whenever m == 0);
+//   * pending complements are a carry: the n emitted bits `top` preceded by... first, p complements, rest  ==  the
+//     (n+p)-bit number  top + (ones(p) << (n-1)).
+// Anything outside the common case (zero-width interval, n > 30, more than 32 bits to emit) re-runs the literal path.
+template <class Sink>
+L3C_HD void encode_symbol_lean(uint32_t &low, uint32_t &high, uint32_t &pending, uint32_t w, Sink &sink) {
+    const uint32_t c_lo = interval_lo(w), c_hi = interval_hi(w);
+    const uint32_t range = high - low;
+    const uint32_t hi1 = low - 1u + (uint32_t)(((uint64_t)range * c_hi + c_hi) >> 16);
+    const uint32_t lo1 = low + (uint32_t)(((uint64_t)range * c_lo + c_lo) >> 16);
+    const uint32_t x = lo1 ^ hi1;
+    const int n = clz32(x);
+    if (__builtin_expect(n > 30 || (uint32_t)n + pending > 32u, 0)) {
+        encode_symbol(low, high, pending, c_lo, c_hi, sink);
+        return;
+    }
+    const uint32_t t = lo1 & ~hi1;
+    const int m = clz32(~(t << (n + 1)));
+    const int k = n + m;                                  // <= 31
+    low = (lo1 << k) & 0x7FFFFFFFu;
+    high = (hi1 << k) | ones(k) | 0x80000000u;
+    const uint32_t top = lo1 >> ((32 - n) & 31);
+    const uint32_t carry = ones((int)pending) << ((n - 1) & 31);
+    const uint32_t v = n ? top + carry : 0u;
+    const uint32_t total = n ? (uint32_t)n + pending : 0u;
+    sink.put(v, (int)total);
+    pending = (n ? 0u : pending) + (uint32_t)m;
+}
+
+
+// ---- two-phase encoder ---------------------------------------------------------------------------------------------------
+// Phase 1 (serial per stream, branch-free): only the interval recurrence.  Per symbol it produces a record
+//     rec_lo = low' (the lower bound right after the interval update, before renormalisation)
+//     rec_nm = n | m << 8      n = length of the common prefix of low'/high' (0..32), m = underflow run (0..31)
+// which is everything the bitstream depends on: the symbol emits -- iff n > 0 -- the top n bits of low', the first of them
+// followed by the complements owed for the `pending` underflow bits accumulated since the previous emitting symbol, and then
+// sets pending = m (or adds m when n == 0).  Phase 2 turns records into bits and is parallel over symbols: pending is a
+// segmented sum of m, bit offsets are a prefix sum of the emitted lengths (csrc/ac_kernels.hip: ac_pack_kernel).
+L3C_HD void encode_state_step(uint32_t &low, uint32_t &high, uint32_t w, uint32_t &rec_lo, uint32_t &rec_nm) {
+    const uint32_t c_lo = interval_lo(w), c_hi = interval_hi(w);
+    const uint32_t range = high - low;
+    const uint32_t hi1 = low - 1u + (uint32_t)(((uint64_t)range * c_hi + c_hi) >> 16);
+    const uint32_t lo1 = low + (uint32_t)(((uint64_t)range * c_lo + c_lo) >> 16);
+    int n, m;
+    renorm_counts(lo1, hi1, n, m, low, high);
+    rec_lo = lo1;
+    rec_nm = (uint32_t)n | ((uint32_t)m << 8);
+}
+
+// Packed record: top n bits of low' in bits 10.., n in bits 5..9, m in bits 0..4.  After renormalisation the interval is
+// wider than 2^30 and c_high > c_low, so low' and high' differ by >= 2^14 - 2 and share at most 18 leading bits: for every
+// valid (strictly increasing) table n <= 18 and the record fits 28 bits.  Tables with c_high <= c_low are outside the
+// contract of the encoder (the reference produces an undecodable stream for them too).
+L3C_HD uint32_t pack_record(uint32_t rec_lo, uint32_t rec_nm) {
+    const uint32_t n = rec_nm & 0xFFu, m = rec_nm >> 8;
+    const uint32_t top = n ? rec_lo >> ((32u - n) & 31u) : 0u;
+    return (top << 10) | ((n & 31u) << 5) | (m & 31u);
+}
+L3C_HD uint32_t record_n(uint32_t r) { return (r >> 5) & 31u; }
+L3C_HD uint32_t record_m(uint32_t r) { return r & 31u; }
+L3C_HD uint32_t record_top(uint32_t r) { return r >> 10; }
+
+// Literal (serial) emission of one record -- the definition phase 2 must reproduce; also used for its rare long runs.
+template <class Sink>
+L3C_HD void emit_record(uint32_t rec_lo, uint32_t rec_nm, uint32_t &pending, Sink &sink) {
+    const int n = (int)(rec_nm & 0xFFu), m = (int)(rec_nm >> 8);
+    if (n) {
+        put_with_pending(sink, rec_lo >> 31, pending);
+        if (n > 1) sink.put((rec_lo << 1) >> (33 - n), n - 1);
+        pending = (uint32_t)m;
+    } else {
+        pending += (uint32_t)m;
+    }
+}
+
 }  // namespace l3c
 #endif

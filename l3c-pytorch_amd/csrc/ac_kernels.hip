@@ -1,9 +1,11 @@
 // ac_kernels.hip -- range coder on the GPU (replaces the CPU coder of torchac.cpp).
 //
 //   intervals_from_table_kernel   table + symbols -> packed (c_low, c_high) words          (fully parallel)
-//   ac_encode_kernel              one stream per LANE, 64 streams per wavefront: the serial integer state machine of
-//                                 csrc/ac_core.h on pre-computed intervals; interval words are read 16 at a time
-//                                 (4 x dwordx4, prefetched one group ahead), output words are written per lane
+//   ac_state_kernel               encoder phase 1, one stream per LANE (64 streams per wavefront): only the serial interval
+//                                 recurrence of csrc/ac_core.h, branch-free; each interval word is replaced in place by
+//                                 a record (top bits, n, m)
+//   ac_pack_kernel                encoder phase 2, one stream per WAVEFRONT, 64 symbols per step: pending runs by a segmented
+//                                 wave scan, bit offsets by a prefix sum, bits merged with LDS atomics, words written coalesced
 //   ac_decode_kernel              one stream per WAVEFRONT: lanes hold the CDF row of the current symbol (prefetched 4
 //                                 symbols ahead); `count` is ranked against the row with v_cmp + s_bcnt1 (ballot/popcount)
 //                                 or, for tables not known to be monotone, with the reference's literal binary search
@@ -38,64 +40,189 @@ __global__ __launch_bounds__(256) void intervals_from_table_kernel(const uint16_
     }
 }
 
-struct LaneStore {
+// ---- encoder, phase 1: interval recurrence, one stream per lane ---------------------------------------------------------
+// Reads 16 interval words at a time (4 x dwordx4, next group prefetched) and overwrites each with its record
+// (csrc/ac_core.h: pack_record) -- same address, so no extra memory and no read/write hazard (a lane only ever touches its
+// own 64-word runs, in order).
+__global__ __launch_bounds__(64) void ac_state_kernel(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
+                                                      uint32_t *__restrict__ final_low) {
+    int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool active = s < n_streams;
+    if (!active) s = n_streams - 1;   // keep the wavefront converged; duplicates rewrite identical values
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    __builtin_amdgcn_s_setprio(3);    // a few long-lived latency-bound waves next to MFMA-heavy kernels: issue first
+
+    // One 64-symbol block (16 x dwordx4 per lane) is processed while the next one is already in flight: ~8 us of serial
+    // work per block hides the HBM latency even when the conv kernels of the next batch saturate the memory system.
+    const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
+    auto chunk_ptr = [&](int64_t c) { return reinterpret_cast<uint4 *>(iv + (c * n_streams + s) * kChunk); };
+    uint4 cur[16], nxt[16];
+    {
+        const uint4 *p = chunk_ptr(0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cur[k] = p[k];
+    }
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        if (c + 1 < n_chunks) {
+            const uint4 *p = chunk_ptr(c + 1);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) nxt[k] = p[k];
+        }
+        uint4 *dst = chunk_ptr(c);
+        const int64_t left = n_sym - c * kChunk;
+        if (left >= kChunk) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t rl, rn;
+                    l3c::encode_state_step(low, high, w[j], rl, rn);
+                    w[j] = l3c::pack_record(rl, rn);
+                }
+                if (active) dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        } else {   // ragged last block
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t rl = 0, rn = 0;
+                    if (k * 4 + j < (int)left) l3c::encode_state_step(low, high, w[j], rl, rn);   // wave-uniform test
+                    w[j] = l3c::pack_record(rl, rn);
+                }
+                if (active) dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    }
+    if (active) final_low[s] = low;
+}
+
+// ---- encoder, phase 2: records -> bits, one stream per wavefront, 64 symbols per step ------------------------------------
+struct GlobalWordStore {
     uint32_t *words;
-    bool active;
+    bool on;
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t w) const {
-        if (active) words[i] = w;
+        if (on) words[i] = w;
     }
 };
 
-__global__ __launch_bounds__(64) void ac_encode_kernel(const uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
-                                                       uint8_t *__restrict__ out, int64_t out_stride,
-                                                       uint32_t *__restrict__ out_nbytes) {
-    int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    const bool active = s < n_streams;
-    if (!active) s = n_streams - 1;  // keep the wavefront converged; stores are predicated
-    l3c::WordSink<LaneStore> sink(LaneStore{reinterpret_cast<uint32_t *>(out + s * out_stride), active});
-    uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+__device__ __forceinline__ uint32_t wave_shfl_up(uint32_t v, int d, int lane) {
+    const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
+    return lane >= d ? o : 0u;
+}
 
-    const int64_t n_groups = (n_sym + 15) / 16;  // groups of 16 symbols; 4 groups per 64-symbol block
-    auto group_ptr = [&](int64_t g) {
-        return reinterpret_cast<const uint4 *>(iv + ((g >> 2) * n_streams + s) * kChunk + (g & 3) * 16);
-    };
-    uint4 cur[4], nxt[4];
+__global__ __launch_bounds__(64) void ac_pack_kernel(const uint32_t *__restrict__ rec, int64_t n_streams, int64_t n_sym,
+                                                     const uint32_t *__restrict__ final_low, uint8_t *__restrict__ out,
+                                                     int64_t out_stride, uint32_t *__restrict__ out_nbytes) {
+    __shared__ uint32_t buf[80];   // the bits of one 64-symbol step: <= 31 carried + 64 * 32 new = 2079 bits = 65 words
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    uint32_t *words = reinterpret_cast<uint32_t *>(out + s * out_stride);
+    uint32_t pending = 0;          // wave-uniform
+    uint64_t bit_off = 0;          // bits emitted so far (wave-uniform)
+    uint32_t carry_word = 0;       // the incomplete output word, MSB aligned
+
+    const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
+    constexpr int PF = 8;          // records in flight: 8 steps of 64 symbols
+    uint32_t ring[PF];
+#pragma unroll
+    for (int d = 0; d < PF; ++d) ring[d] = d < n_chunks ? rec[((int64_t)d * n_streams + s) * kChunk + lane] : 0u;
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += PF)
+#pragma unroll
+    for (int d = 0; d < PF; ++d) {
+        const int64_t c = c0 + d;
+        if (c >= n_chunks) break;   // wave-uniform
+        const uint32_t r = (c * kChunk + lane < n_sym) ? ring[d] : 0u;   // a zero record emits nothing
+        if (c + PF < n_chunks) ring[d] = rec[((c + PF) * n_streams + s) * kChunk + lane];
+        const uint32_t n = l3c::record_n(r), m = l3c::record_m(r), top = l3c::record_top(r);
+        const bool emits = n != 0;
+        // segmented inclusive scan: S_j = emits_j ? m_j : S_{j-1} + m_j  (a run of pending bits restarts at every emitter)
+        uint32_t val = m;
+        uint32_t flag = emits ? 1u : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t v_up = wave_shfl_up(val, d, lane);
+            const uint32_t f_up = wave_shfl_up(flag, d, lane);
+            if (!flag) val += v_up;
+            flag |= f_up;
+        }
+        if (!flag) val += pending;                     // no emitter at or before this lane: the carried run continues
+        // pending BEFORE symbol j = S_{j-1} (exclusive), S_{-1} = carried pending
+        uint32_t p_before = (uint32_t)__shfl_up((int)val, 1, 64);
+        if (lane == 0) p_before = pending;
+        const uint32_t e = emits ? n + p_before : 0u;  // bits this symbol emits
+        const uint32_t new_pending = (uint32_t)__builtin_amdgcn_readlane((int)val, 63);
+
+        if (__builtin_expect(__any(e > 32u), 0)) {
+            // a pending run of >= 15 bits: emit this step serially through the literal path (wave-uniform control flow)
+            const uint32_t nb = (uint32_t)(bit_off & 31u);
+            l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
+            sink.nwords = (uint32_t)(bit_off >> 5);
+            sink.nb = (int)nb;
+            sink.acc = nb ? (uint64_t)(carry_word >> (32u - nb)) : 0u;
+            uint32_t pend = pending;
+            for (int j = 0; j < 64; ++j) {
+                const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)r, j);
+                const uint32_t nj = l3c::record_n(rj);
+                const uint32_t lo_j = nj ? l3c::record_top(rj) << ((32u - nj) & 31u) : 0u;
+                l3c::emit_record(lo_j, nj | (l3c::record_m(rj) << 8), pend, sink);
+            }
+            bit_off = (uint64_t)sink.nwords * 32u + (uint32_t)sink.nb;
+            carry_word = sink.nb ? (uint32_t)(sink.acc << (32 - sink.nb)) : 0u;
+            pending = pend;
+            continue;
+        }
+
+        // exclusive prefix sum of e -> bit position of every symbol inside this step's window
+        uint32_t incl = e;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) incl += wave_shfl_up(incl, d, lane);
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t base = (uint32_t)(bit_off & 31u);
+        const uint32_t pos = base + incl - e;
+        // value: top n bits with the pending complements inserted after the first = top + (ones(p) << (n-1))
+        const uint32_t v = emits ? top + (l3c::ones((int)p_before) << ((n - 1u) & 31u)) : 0u;
+
+        buf[lane] = lane == 0 ? carry_word : 0u;
+        if (lane < 16) buf[64 + lane] = 0u;
+        __syncthreads();
+        if (e) {
+            const uint32_t wi = pos >> 5;
+            const int sh = 32 - (int)(pos & 31u) - (int)e;
+            if (sh >= 0) {
+                atomicOr(&buf[wi], v << sh);
+            } else {
+                atomicOr(&buf[wi], v >> (-sh));
+                atomicOr(&buf[wi + 1], v << (32 + sh));
+            }
+        }
+        __syncthreads();
+        const uint32_t window_bits = base + total;
+        const uint32_t full = window_bits >> 5;        // complete words in the window (<= 65)
+        const uint32_t first_word = (uint32_t)(bit_off >> 5);
+        if ((uint32_t)lane < full) words[first_word + lane] = l3c::bswap32(buf[lane]);
+        if ((uint32_t)lane + 64u < full) words[first_word + 64 + lane] = l3c::bswap32(buf[64 + lane]);
+        carry_word = (window_bits & 31u) ? buf[full] : 0u;
+        __syncthreads();
+        bit_off += total;
+        pending = new_pending;
+    }
+    // flush (torchac.cpp:209-219): pending + 1 complements after the quadrant bit, zero padding to a byte
     {
-        const uint4 *p = group_ptr(0);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = p[k];
+        const uint32_t nb = (uint32_t)(bit_off & 31u);
+        l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
+        sink.nwords = (uint32_t)(bit_off >> 5);
+        sink.nb = (int)nb;
+        sink.acc = nb ? (uint64_t)(carry_word >> (32u - nb)) : 0u;
+        uint32_t pend = pending;
+        l3c::encode_finish(final_low[s], pend, sink);
+        const uint32_t nbytes = sink.finish();
+        if (lane == 0) out_nbytes[s] = nbytes;
     }
-    const int64_t full_groups = n_sym / 16;
-    for (int64_t g = 0; g < full_groups; ++g) {
-        if (g + 1 < n_groups) {
-            const uint4 *p = group_ptr(g + 1);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) nxt[k] = p[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) cur[k] = nxt[k];
-    }
-    if (full_groups < n_groups) {   // ragged tail (< 16 symbols), already in `cur`
-        const int valid = (int)(n_sym - full_groups * 16);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k * 4 + j < valid)
-                    l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
-        }
-    }
-    l3c::encode_finish(low, pending, sink);
-    const uint32_t nbytes = sink.finish();
-    if (active) out_nbytes[s] = nbytes;
 }
 
 // ---- decoder -------------------------------------------------------------------------------------------------------
@@ -265,17 +392,24 @@ int l3c_ac_intervals_from_table(const uint16_t *cdf, int64_t row_stride, int Lp,
     return l3c::check_launch("intervals_from_table_kernel");
 }
 
-int l3c_ac_encode(const uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride_bytes,
-                  uint32_t *out_nbytes, l3c_stream_t stream) {
-    L3C_REQUIRE(intervals && out && out_nbytes, "null pointer");
-    L3C_REQUIRE(n_streams > 0 && n_sym > 0, "empty input");
+int64_t l3c_ac_encode_workspace_bytes(int64_t n_streams) { return ((n_streams * 4 + 255) / 256) * 256; }
+
+int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride_bytes,
+                  uint32_t *out_nbytes, void *workspace, l3c_stream_t stream) {
+    L3C_REQUIRE(intervals && out && out_nbytes && workspace, "null pointer");
+    L3C_REQUIRE(n_streams > 0 && n_sym > 0 && n_streams < (1ll << 31), "empty input");
     L3C_REQUIRE(out_stride_bytes % 4 == 0 && out_stride_bytes >= l3c_ac_max_bytes(n_sym), "output stride too small");
-    L3C_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0 && (reinterpret_cast<uintptr_t>(intervals) & 15) == 0,
-                "misaligned buffer");
+    L3C_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0 && (reinterpret_cast<uintptr_t>(intervals) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(workspace) & 3) == 0, "misaligned buffer");
+    uint32_t *final_low = static_cast<uint32_t *>(workspace);
     const int blocks = (int)((n_streams + 63) / 64);
-    hipLaunchKernelGGL(ac_encode_kernel, dim3(blocks), dim3(64), 0, l3c::as_stream(stream), intervals, n_streams, n_sym,
-                       out, out_stride_bytes, out_nbytes);
-    return l3c::check_launch("ac_encode_kernel");
+    hipLaunchKernelGGL(ac_state_kernel, dim3(blocks), dim3(64), 0, l3c::as_stream(stream), intervals, n_streams, n_sym,
+                       final_low);
+    int rc = l3c::check_launch("ac_state_kernel");
+    if (rc != L3C_OK) return rc;
+    hipLaunchKernelGGL(ac_pack_kernel, dim3((unsigned)n_streams), dim3(64), 0, l3c::as_stream(stream), intervals,
+                       n_streams, n_sym, final_low, out, out_stride_bytes, out_nbytes);
+    return l3c::check_launch("ac_pack_kernel");
 }
 
 int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t *in, const int64_t *in_offsets,

@@ -62,7 +62,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
 }
 
 template <int KS, int STRIDE, int DIL, int CK, int MT>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p) {
     using G = Geo<KS, STRIDE, DIL, CK, MT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
 
@@ -94,16 +94,30 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     for (int cc = 0; cc < n_cc; ++cc) {
         if (cc) __syncthreads();  // everyone is done reading the previous chunk
         // ---- stage the input patch: [IH][IW] pixels x CK channels, zero outside the image ----
+        // All global loads of the chunk are issued before the first LDS write (one memory round trip per chunk, not one
+        // per iteration); the ~NIT*4 staging VGPRs are dead again before the MFMA loop starts.
         constexpr int V = CK / 4;  // float4 per pixel
-        for (int i = tid; i < G::IH * G::IW * V; i += 256) {
+        constexpr int TOTAL = G::IH * G::IW * V;
+        constexpr int NIT = (TOTAL + 255) / 256;
+        f32x4 stage[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
             const int c4 = i % V, pix = i / V;
             const int r = pix / G::IW, ci = pix % G::IW;
             const int iy = iy0 + r, ix = ix0 + ci;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
+            if (i < TOTAL && !(p.epilogue & 256) && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win)
                 v = *reinterpret_cast<const f32x4 *>(in_b + ((size_t)iy * p.Win + ix) * p.in_cstride + cc * CK + c4 * 4);
+            stage[it] = v;
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int c4 = i % V, pix = i / V;
+            const int r = pix / G::IW, ci = pix % G::IW;
             const int lc = STRIDE == 2 ? (ci & 1) * G::IWH + (ci >> 1) : ci;
-            *reinterpret_cast<f32x4 *>(&lds[(r * G::IWL + lc) * G::PS + c4 * 4]) = v;
+            if (i < TOTAL) *reinterpret_cast<f32x4 *>(&lds[(r * G::IWL + lc) * G::PS + c4 * 4]) = stage[it];
         }
         __syncthreads();
 
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                 const int gabs = cc * (CK / 8) + g;
                 f32x4 bfrag[2];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) bfrag[nt] = wp[((size_t)(gabs * G::TAPS + tap) * 2 + nt) * 64];
+                for (int nt = 0; nt < 2; ++nt) bfrag[nt] = wp[(p.epilogue & 512) ? 0 : ((size_t)(gabs * G::TAPS + tap) * 2 + nt) * 64];
                 f32x4 afrag[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
@@ -137,6 +151,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel within the row) ----
     const bool relu = p.epilogue & L3C_EPI_RELU;
     const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
+    const bool interior = oy0 + G::TH <= p.Hout && ox0 + TW <= p.Wout && chunk_o * 64 + 64 <= p.Cout;
+    if (interior && !shuffle) {
+        // whole tile inside the image: no per-element bounds checks, 32-bit offsets from block-uniform bases
+        float *obase = p.out + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + chunk_o * 64;
+        const float *rbase = p.res ? p.res + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.res_cstride + p.res_coff + chunk_o * 64 : nullptr;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bias = p.bias[chunk_o * 64 + nt * 32 + lx];
+            float resv[MT][16];
+            if (rbase) {   // all residual loads of this half in flight before the first use
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pix = (wave * MT + mt) * p.Wout + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        resv[mt][r] = rbase[pix * p.res_cstride + nt * 32 + lx];
+                    }
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int pix = (wave * MT + mt) * p.Wout + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if ((p.epilogue & 1024) && acc[mt][nt][r] != 12345.f) continue;
+                    float v = acc[mt][nt][r] + bias;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    if (rbase) v = v + resv[mt][r];
+                    obase[pix * p.out_cstride + nt * 32 + lx] = v;
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int co = chunk_o * 64 + nt * 32 + lx;
@@ -281,8 +327,8 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
     if (rc != L3C_OK) return rc;
     L3C_REQUIRE(d->Cin % 16 == 0, "Cin must be a multiple of 16");
     hipStream_t s = l3c::as_stream(stream);
-    if (d->KS == 3 && d->dilation == 1) return launch<3, 1, 1, 32, 2>(p, s);
-    if (d->KS == 3 && d->dilation == 2) return launch<3, 1, 2, 32, 2>(p, s);
+    if (d->KS == 3 && d->dilation == 1) return (d->epilogue & 2048) ? launch<3, 1, 1, 32, 2>(p, s) : launch<3, 1, 1, 16, 2>(p, s);
+    if (d->KS == 3 && d->dilation == 2) return launch<3, 1, 2, 16, 2>(p, s);
     if (d->KS == 3 && d->dilation == 4) return launch<3, 1, 4, 16, 2>(p, s);
     if (d->KS == 5) return launch<5, 2, 1, 16, 1>(p, s);
     return launch<1, 1, 1, 32, 2>(p, s);

@@ -34,4 +34,28 @@ int l3c_device_info(char *name_host, int name_cap, int *num_cu_host, char *arch_
     if (num_cu_host) *num_cu_host = prop.multiProcessorCount;
     return L3C_OK;
 }
+
+int l3c_stream_create_cu_range(int first_cu, int n_cu, l3c_stream_t *stream_out_host) {
+    L3C_REQUIRE(stream_out_host, "null pointer");
+    int dev = 0;
+    int rc = l3c::check_hip(hipGetDevice(&dev), "hipGetDevice");
+    if (rc != L3C_OK) return rc;
+    hipDeviceProp_t prop;
+    rc = l3c::check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties");
+    if (rc != L3C_OK) return rc;
+    const int total = prop.multiProcessorCount;
+    L3C_REQUIRE(first_cu >= 0 && n_cu > 0 && first_cu + n_cu <= total, "CU range outside the device");
+    uint32_t mask[32] = {0};
+    L3C_REQUIRE(total <= 32 * 32, "device has more CUs than the mask holds");
+    for (int cu = first_cu; cu < first_cu + n_cu; ++cu) mask[cu >> 5] |= 1u << (cu & 31);
+    hipStream_t st = nullptr;
+    rc = l3c::check_hip(hipExtStreamCreateWithCUMask(&st, (uint32_t)((total + 31) / 32), mask), "hipExtStreamCreateWithCUMask");
+    if (rc != L3C_OK) return rc;
+    *stream_out_host = reinterpret_cast<l3c_stream_t>(st);
+    return L3C_OK;
+}
+
+int l3c_stream_destroy(l3c_stream_t stream) {
+    return l3c::check_hip(hipStreamDestroy(l3c::as_stream(stream)), "hipStreamDestroy");
+}
 }

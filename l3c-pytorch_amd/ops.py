@@ -172,11 +172,12 @@ def intervals_from_table(cdf, sym, n_streams, n_sym, broadcast_row=False):
 
 
 def ac_encode(iv, n_streams, n_sym):
-    """-> (out uint8 (n_streams, stride), nbytes int32 (n_streams,)) on the device."""
+    """-> (out uint8 (n_streams, stride), nbytes int32 (n_streams,)) on the device.  `iv` is clobbered."""
     stride = _lib.load().l3c_ac_max_bytes(n_sym)
     out = torch.empty(n_streams, stride, dtype=torch.uint8, device=iv.device)
     nbytes = torch.empty(n_streams, dtype=torch.int32, device=iv.device)
-    call('l3c_ac_encode', ptr(iv), n_streams, n_sym, ptr(out), stride, ptr(nbytes), stream())
+    ws = torch.empty(_lib.load().l3c_ac_encode_workspace_bytes(n_streams), dtype=torch.uint8, device=iv.device)
+    call('l3c_ac_encode', ptr(iv), n_streams, n_sym, ptr(out), stride, ptr(nbytes), ptr(ws), stream())
     return out, nbytes
 
 

@@ -39,7 +39,7 @@ def test_pure_host_entry_points():
 
 def test_argument_errors_are_reported_not_crashed():
     lib = _lib.load()
-    rc = lib.l3c_ac_encode(None, 1, 1, None, 0, None, None)
+    rc = lib.l3c_ac_encode(None, 1, 1, None, 0, None, None, None)
     assert rc == -1 and b'null pointer' in lib.l3c_last_error()
     with pytest.raises(_lib.L3CError):
         _lib.check(rc)

@@ -15,7 +15,7 @@ struct NullStore {
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t w) const { if (w == 0x12345u && i == 77777777u) *sinkhole = w; }
 };
 
-template <int MODE>   // 0: full, 1: no stores, 2: no loads (intervals synthesised from a register LCG), 3: no loads no stores
+template <int MODE, int LEAN>   // 0: full, 1: no stores, 2: no loads (intervals synthesised from a register LCG), 3: no loads no stores
 __global__ __launch_bounds__(64) void enc(const uint32_t *__restrict__ iv, int64_t S, int64_t N, uint8_t *out, int64_t stride, uint32_t *nb) {
     int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
     const bool active = s < S;
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(64) void enc(const uint32_t *__restrict__ iv, int64
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (MODE >= 2) { lcg = lcg * 1664525u + 1013904223u; uint32_t lo = (lcg >> 8) & 0xFF00u; w[j] = lo | ((lo + 255u) << 16); }
-                    l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
+                    if (LEAN) l3c::encode_symbol_lean(low, high, pending, w[j], sink);
+                    else l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
                 }
             }
             if (MODE < 2) { for (int k = 0; k < 4; ++k) cur[k] = nxt[k]; }
@@ -64,7 +65,7 @@ int main() {
     const int64_t words = (N / 64) * S * 64;
     std::vector<uint32_t> h(words);
     uint32_t x = 1;
-    for (auto &w : h) { x = x * 1664525u + 1013904223u; uint32_t lo = (x >> 8) & 0xFF00u; w = lo | ((lo + 255u) << 16); }   // ~8 bits/symbol
+    for (auto &w : h) { x = x * 1664525u + 1013904223u; uint32_t bits = 2 + ((x >> 28) % 13); uint32_t width = 65536u >> bits; uint32_t lo = ((x >> 4) % (65536u - width)); w = lo | ((lo + width - 1u) << 16); }   // 2..14 bits/symbol
     uint32_t *iv; uint8_t *out; uint32_t *nb;
     const int64_t stride = ((2 * N + 19) / 4) * 4 + 8;
     hipMalloc(&iv, words * 4); hipMalloc(&out, S * stride); hipMalloc(&nb, S * 4);
@@ -76,10 +77,10 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-28s %8.2f ms  %7.1f ns/symbol\n", name, ms, ms * 1e6 / N);
     };
-    time("full", [&] { hipLaunchKernelGGL(enc<0>, dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
-    time("no stores", [&] { hipLaunchKernelGGL(enc<1>, dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
-    time("no loads", [&] { hipLaunchKernelGGL(enc<2>, dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
-    time("no loads, no stores", [&] { hipLaunchKernelGGL(enc<3>, dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("fast full", [&] { hipLaunchKernelGGL((enc<0, 0>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("lean full", [&] { hipLaunchKernelGGL((enc<0, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("lean no stores", [&] { hipLaunchKernelGGL((enc<1, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("lean no loads no stores", [&] { hipLaunchKernelGGL((enc<3, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
     uint32_t *o; hipMalloc(&o, 256);
     const int iters = 1 << 20;
     hipLaunchKernelGGL(chain, dim3(1), dim3(64), 0, 0, o, iters); hipDeviceSynchronize();
