@@ -159,3 +159,30 @@ def test_auto_crop_parts(blueprint, tmp_path, monkeypatch):
     assert parts == ['big.l3c.part0', 'big.l3c.part1', 'big.l3c.part2', 'big.l3c.part3']
     back = bc.decode(p + '.part2')
     assert torch.equal(back.cpu(), img) and bpsp > 0
+
+
+def test_l3c_cli_enc_dec_roundtrip(synthetic_l3c, tmp_path):
+    """`python l3c.py LOG_DIR LOG_DATE enc IMG OUT` / `dec OUT PNG` (reference l3c.py:74-125) on a synthetic experiment dir."""
+    import importlib.util
+    from PIL import Image
+    from l3c_pytorch_amd.helpers import synthetic
+    cfg, sd = synthetic_l3c
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = tmp_path / 'logs' / '0306_0001 cr oi' / 'ckpts'
+    exp.mkdir(parents=True)
+    torch.save({'net': sd}, str(exp / 'ckpt_0000000001.pt'))
+    img = synthetic.make_image(45, 70, 21, 'natural')
+    src = str(tmp_path / 'in.png')
+    Image.fromarray(img.permute(1, 2, 0).numpy()).save(src)
+    spec = importlib.util.spec_from_file_location('l3c_cli', os.path.join(root, 'l3c.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    out = str(tmp_path / 'out.l3c')
+    assert cli.main([str(tmp_path / 'logs'), '0306_0001', 'enc', src, out]) == 0
+    assert os.path.getsize(out) > 116
+    assert cli.main([str(tmp_path / 'logs'), '0306_0001', 'enc', src, out]) == 1          # exists, no --overwrite
+    assert cli.main([str(tmp_path / 'logs'), '0306_0001', 'enc', src, out, '-f']) == 0
+    png = str(tmp_path / 'dec.png')
+    assert cli.main([str(tmp_path / 'logs'), '0306_0001', 'dec', out, png]) == 0
+    back = torch.from_numpy(np.array(Image.open(png))).permute(2, 0, 1)
+    assert torch.equal(back, img)

@@ -1,0 +1,106 @@
+"""Host-side logic (no GPU): config parser, padding, auto-crop, part suffixes, experiment-dir conventions, the uniform table,
+the schema, container framing."""
+import os
+
+import pytest
+import torch
+
+import l3c_pytorch_amd  # noqa: F401
+from l3c_pytorch_amd import auto_crop
+from l3c_pytorch_amd.bitcoding import part_suffix_helper as psh
+from l3c_pytorch_amd.bitcoding.bitcoding import uniform_cdf_row
+from l3c_pytorch_amd.helpers import config_parser, pad, paths, synthetic
+from l3c_pytorch_amd.modules import quantizer, schema
+
+
+def test_config_parser_inheritance_and_api(tmp_path):
+    cfg = config_parser.parse_builtin('ms', 'cr_rgb')
+    assert cfg.num_scales == 3 and cfg.q.C == 3 and cfg.q.L == 5 and cfg.dec.skip is True
+    assert cfg.enc.cls == 'BicubicSubsampling' and cfg.prob.K == 10       # inherited through two `use` levels
+    kv = dict(cfg.all_params_and_values())
+    assert kv['q.levels_range'] == (-1, 1) and kv['lr.initial'] == 0.0001
+    cfg.set_attr('q.L', 7)
+    assert cfg.q.L == 7
+    p = tmp_path / 'x.cf'
+    p.write_text('a = 1\nb.c = "x"  # comment\n# full comment\nbad line\n')
+    with pytest.raises(ValueError):
+        config_parser.parse(str(p))
+    with pytest.raises(FileNotFoundError):
+        config_parser.parse(str(tmp_path / 'nope.cf'))
+
+
+def test_pad_matches_reference_semantics():
+    img = torch.arange(3 * 37 * 51).reshape(1, 3, 37, 51)
+    out, t = pad.pad(img, 8, mode='constant')
+    assert out.shape[-2:] == (40, 56) and t == (2, 3, 1, 2)               # left, right, top, bottom
+    assert torch.equal(pad.undo_pad(out, *t), img)
+    same, ident = pad.pad(out, 8)
+    assert same is out and ident(5) == 5
+
+
+def test_auto_crop_counts_and_stitch():
+    for H, W, n in [(100, 60, 64), (49, 33, 16), (20, 20, 4), (10, 10, 1)]:
+        img = torch.arange(3 * H * W).reshape(1, 3, H, W)
+        crops = list(auto_crop.iter_crops(img, 210))
+        assert len(crops) == n, (H, W, len(crops))
+        if n > 1:
+            assert torch.equal(auto_crop.stitch(crops), img)
+    assert not auto_crop.needs_crop(torch.zeros(1, 3, 1500, 2000))        # strictly greater (auto_crop.py:47)
+    assert auto_crop.needs_crop(torch.zeros(1, 3, 1500, 2001))
+    c = auto_crop.CropLossCombinator()
+    c.add(2.0, 100)
+    c.add(4.0, 300)
+    assert abs(c.get_bpsp() - 3.5) < 1e-12
+
+
+def test_part_suffixes(tmp_path):
+    assert psh.make_part_suffix(10) == '.part10' and psh.contains_part_suffix('a/b.part3')
+    assert not psh.contains_part_suffix('a/b.part3/more') and psh.index_of_part_suffix('x.part12') == 12
+    for i in range(12):
+        (tmp_path / ('some.file' + psh.make_part_suffix(i))).write_text('x')
+    got = psh.iter_part_suffixes(str(tmp_path / 'some.file.part3'))
+    assert [os.path.basename(p) for p in got] == ['some.file.part{}'.format(i) for i in range(12)]
+
+
+def test_uniform_row_and_quantiser_maps():
+    assert uniform_cdf_row(25).numpy().view('uint16').tolist()[:6] == [0, 2621, 5243, 7864, 10486, 13107]
+    assert uniform_cdf_row(25).numpy().view('uint16').tolist()[-2:] == [62915, 0]
+    assert uniform_cdf_row(256).numpy().view('uint16').tolist()[:3] == [0, 256, 512]
+    S = torch.arange(25)
+    bn = quantizer.to_bn(S, -1, 1, 25)
+    assert torch.equal(quantizer.to_sym(bn, -1, 1, 25), S)
+    assert torch.equal(synthetic.quantiser_levels((-1, 1), 25), bn)
+
+
+def test_experiment_dir_conventions(tmp_path):
+    cfg = config_parser.parse_builtin('ms', 'cr')
+    exp = tmp_path / '0306_0001 cr oi'
+    (exp / 'ckpts').mkdir(parents=True)
+    sd = synthetic.make_state_dict(cfg, 0)
+    torch.save({'net': sd}, str(exp / 'ckpts' / 'ckpt_0000000010.pt'))
+    torch.save({'net': sd}, str(exp / 'ckpts' / 'ckpt_0000000020.pt.tmp'))
+    d = paths.get_experiment_dir(str(tmp_path), '0306_0001')
+    assert d == str(exp)
+    comps = paths.parse_log_dir(d, config_parser.CONFIG_DIR)
+    assert comps.config_paths[0].endswith(os.path.join('ms', 'cr.cf')) and comps.postfix is None
+    assert paths.get_ckpt_for_itr(paths.get_ckpts_dir(d), -1)[0] == 20
+    assert paths.get_ckpt_for_itr(paths.get_ckpts_dir(d), 5)[0] == 10
+    with pytest.raises(ValueError):
+        paths.get_experiment_dir(str(tmp_path), '0101_0000')
+    assert paths.parse_log_dir(str(tmp_path / '0306_0002 cr oi lr.initial=0.1'), config_parser.CONFIG_DIR).postfix == ('lr.initial=0.1',)
+
+
+def test_schema_strict_checks(synthetic_l3c):
+    cfg, sd = synthetic_l3c
+    schema.check_state_dict(sd, cfg)
+    bad = dict(sd)
+    bad['extra.weight'] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        schema.check_state_dict(bad, cfg)
+    assert schema.non_shared_get_Kp(10, 3) == 120 and schema.non_shared_get_Kp(10, 5) == 150
+
+
+def test_rgb_baselines_are_refused():
+    from l3c_pytorch_amd.modules.multiscale_network import MultiscaleNetwork
+    with pytest.raises(NotImplementedError):
+        MultiscaleNetwork(config_parser.parse_builtin('ms', 'cr_rgb_shared'))
