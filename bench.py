@@ -146,9 +146,15 @@ def main():
             flops, secs, n = by[dom]
             all_f = sum(v[0] for v in by.values())
             all_s = sum(v[1] for v in by.values())
+            traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_conv3x3.json')) as f:
+                    traffic = int(json.load(f)['hbm_bytes_per_flop'] * flops / n)
+            except (OSError, KeyError, ValueError):
+                pass
             roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(flops / secs / 1e12, 2),
                         'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                        'traffic': None, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
+                        'traffic': traffic, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
                         'algorithmic_gflop_per_launch': round(flops / n / 1e9, 3),
                         'all_mfma_convs': {'achieved': round(all_f / all_s / 1e12, 2), 'seconds_per_step': round(all_s / args.steps, 5),
                                            'share_of_step': round(all_s / elapsed, 3)}}
