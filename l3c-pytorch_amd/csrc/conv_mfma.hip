@@ -1,5 +1,9 @@
 // conv_mfma.hip -- fp32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (gfx950), plus a plain-VALU cross-check.
 //
+// Two kernels: conv_lds_kernel ("v3", all 3x3 layers: both MFMA operands from LDS, weights by LDS-DMA) further down, and
+// conv_mfma_kernel ("v1", 5x5 stride 2 and 1x1: weights per wave from L2) described first.  Flags 0x100..0x800 in
+// `epilogue` select development-probe instantiations / the v1 kernel for A/B measurements (tools/conv_probe.py).
+//
 // Replaces the cuDNN convolutions behind the reference's conv factory (pytorch_ext.py:57-61) for every 64-/192-input-
 // channel layer of the L3C stack: 3x3 (dilation 1, 2, 4), 5x5 stride 2, 1x1; epilogues: bias,
 // ReLU, residual add (edsr.py:83-86, net.py:142, :181), PixelShuffle(2) (edsr.py:98-99).
@@ -39,7 +43,6 @@ struct ConvParams {
     int pad, epilogue;
     int tiles_x, tiles_y, n_chunks_o;
     int total_blocks;      // number of work items (tile x output-channel chunk x image)
-    const float *zero_page;  // >= 16 bytes of zeros (source of out-of-image pixels for the LDS-DMA path)
 };
 
 constexpr int TW = 32;
@@ -244,173 +247,6 @@ __global__ __launch_bounds__(256, (MT >= 4 ? 2 : 3)) void conv_mfma_kernel(const
     }
 }
 
-// ---- v2: persistent blocks, LDS-DMA double-buffered staging (3x3 stride 1) -------------------------------------------------
-// The v1 kernel above stages a chunk, barriers, computes, barriers: co-resident blocks run in lockstep, so the staging round
-// trips and the epilogue leave the MFMA pipe idle (measured: 11 % + 5 %).  Here
-//   * a block is persistent over a contiguous range of work items (tile x 64 output channels x image) and walks a flat
-//     sequence of stages (item, 16-channel chunk);
-//   * stage s+1 is fetched by `global_load_lds_dwordx4` (HBM/L2 -> LDS without VGPRs or ds_write) into the other LDS
-//     buffer while stage s is computed -- one barrier per stage, no prologue bubble between tiles, the epilogue's stores
-//     overlap the next tile's first fetch;
-//   * LDS-DMA writes lane-linear 1 KB runs, so the LDS image is linear (64 B per pixel) and the bank-conflict fix is an XOR
-//     swizzle applied on the SOURCE side: LDS slot q' of pixel p holds channel quad q' ^ ((p >> 2) & 3); any 16 lanes of
-//     a ds_read_b128 group that read the same quad of 16 consecutive pixels then hit 16 distinct 16-byte slots.
-// Out-of-image pixels are fetched from a 256-byte zero page.
-template <int KS, int DIL, int MT>
-__global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
-    constexpr int CK = 16;
-    using G = Geo<KS, 1, DIL, CK, MT>;
-    constexpr int NPIX = G::IH * G::IW;
-    constexpr int NWI = (NPIX * 4 + 63) / 64;    // wave-level DMA instructions per stage (1 KB each)
-    constexpr int BUF = NWI * 256;               // floats per LDS buffer
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int half = lane >> 5, lx = lane & 31;
-    const int n_cc = p.Cin / CK;
-    const int groups_total = p.Cin / 8;
-    const int tiles = p.tiles_x * p.tiles_y;
-
-    // contiguous item range of this block; blocks that share an XCD get neighbouring ranges
-    const int nb = gridDim.x;
-    const int k = xcd_remap(blockIdx.x, nb);
-    const int qi = p.total_blocks / nb, ri = p.total_blocks % nb;
-    const int first = k * qi + (k < ri ? k : ri);
-    const int count = qi + (k < ri ? 1 : 0);
-    const int n_stages = count * n_cc;
-
-    auto issue_dma = [&](int stage) {
-        const int item = first + stage / n_cc, cc = stage % n_cc;
-        const int tile = item % tiles, b = item / tiles / p.n_chunks_o;
-        const int iy0 = (tile / p.tiles_x) * G::TH - p.pad, ix0 = (tile % p.tiles_x) * TW - p.pad;
-        const float *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cstride + p.in_coff + cc * CK;
-        float *dst = lds + (stage & 1) * BUF;
-        for (int j = wave; j < NWI; j += 4) {
-            const int slot = j * 64 + lane;
-            const int pix = slot >> 2;
-            const int q = (slot & 3) ^ ((pix >> 2) & 3);
-            const int r = pix / G::IW, ci = pix % G::IW;
-            const int iy = iy0 + r, ix = ix0 + ci;
-            const bool ok = pix < NPIX && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win;
-            const float *src = ok ? in_b + ((size_t)iy * p.Win + ix) * p.in_cstride + q * 4 : p.zero_page;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(dst + j * 256), 16, 0, 0);
-        }
-    };
-
-    if (n_stages > 0) issue_dma(0);
-    int stage = 0;
-    for (int it = 0; it < count; ++it) {
-        const int item = first + it;
-        const int chunk_o = (item / tiles) % p.n_chunks_o;
-        const f32x4 *wp = reinterpret_cast<const f32x4 *>(p.w) + (size_t)chunk_o * groups_total * G::TAPS * 2 * 64 + lane;
-        f32x16 acc[MT][2];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-
-        for (int cc = 0; cc < n_cc; ++cc, ++stage) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of stage `stage` has landed
-            __syncthreads();                                   // ... everyone's has, and everyone is done with the other buffer
-            if (stage + 1 < n_stages) issue_dma(stage + 1);
-            const float *buf = lds + (stage & 1) * BUF;
-            const f32x4 *wc = wp + (size_t)cc * (CK / 8) * G::TAPS * 2 * 64;
-#pragma unroll
-            for (int tap = 0; tap < G::TAPS; ++tap) {
-                const int ky = tap / KS, kx = tap % KS;
-#pragma unroll
-                for (int g = 0; g < CK / 8; ++g) {
-                    f32x4 bfrag[2];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) bfrag[nt] = wc[((g * G::TAPS + tap) * 2 + nt) * 64];
-                    f32x4 afrag[MT];
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int px = ((wave * MT + mt) + ky * DIL) * G::IW + lx + kx * DIL;
-                        const int qs = (g * 2 + half) ^ ((px >> 2) & 3);
-                        afrag[mt] = *reinterpret_cast<const f32x4 *>(&buf[px * 16 + qs * 4]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(afrag[mt][t], bfrag[nt][t], acc[mt][nt], 0, 0, 0);
-                }
-            }
-        }
-
-        // ---- epilogue of this item (its stores overlap the fetch of the next item's first chunk) ----
-        const int tile = item % tiles, b = item / tiles / p.n_chunks_o;
-        const int oy0 = (tile / p.tiles_x) * G::TH, ox0 = (tile % p.tiles_x) * TW;
-        // keep the per-lane store offsets from being hoisted out of the item loop (128 loop-invariant 64-bit addresses
-        // would live across the MFMA loop and spill): launder the lane coordinates once per item
-        int e_lx = lx, e_half = half, e_wave = wave;
-        asm volatile("" : "+v"(e_lx), "+v"(e_half), "+v"(e_wave));
-        const bool relu = p.epilogue & L3C_EPI_RELU;
-        const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
-        const bool interior = oy0 + G::TH <= p.Hout && ox0 + TW <= p.Wout && chunk_o * 64 + 64 <= p.Cout;
-        if (interior && !shuffle) {
-            float *obase = p.out + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + chunk_o * 64;
-            const float *rbase = p.res ? p.res + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.res_cstride + p.res_coff + chunk_o * 64 : nullptr;
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const float bias = p.bias[chunk_o * 64 + nt * 32 + e_lx];
-                float resv[MT][16];
-                if (rbase) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int pix = (e_wave * MT + mt) * p.Wout + (r & 3) + 8 * (r >> 2) + 4 * e_half;
-                            resv[mt][r] = rbase[pix * p.res_cstride + nt * 32 + e_lx];
-                        }
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int pix = (e_wave * MT + mt) * p.Wout + (r & 3) + 8 * (r >> 2) + 4 * e_half;
-                        float v = acc[mt][nt][r] + bias;
-                        if (relu) v = fmaxf(v, 0.0f);
-                        if (rbase) v = v + resv[mt][r];
-                        obase[pix * p.out_cstride + nt * 32 + e_lx] = v;
-                    }
-            }
-        } else {
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int co = chunk_o * 64 + nt * 32 + e_lx;
-                if (co >= p.Cout) continue;
-                const float bias = p.bias[co];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int oy = oy0 + e_wave * MT + mt;
-                    if (oy >= p.Hout) continue;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * e_half;
-                        if (ox >= p.Wout) continue;
-                        float v = acc[mt][nt][r] + bias;
-                        if (relu) v = fmaxf(v, 0.0f);
-                        if (p.res) v = v + p.res[(((size_t)b * p.Hout + oy) * p.Wout + ox) * p.res_cstride + p.res_coff + co];
-                        if (shuffle) {
-                            const size_t oyy = 2 * oy + ((co >> 1) & 1), oxx = 2 * ox + (co & 1);
-                            p.out[(((size_t)b * 2 * p.Hout + oyy) * 2 * p.Wout + oxx) * p.out_cstride + p.out_coff + (co >> 2)] = v;
-                        } else {
-                            p.out[(((size_t)b * p.Hout + oy) * p.Wout + ox) * p.out_cstride + p.out_coff + co] = v;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
 // ---- v3: weights through LDS ---------------------------------------------------------------------------------------------
 // Measured on the v1 structure (development probes): MFMA + barriers alone run at 146.7 TFLOP/s, adding the LDS A-fragment
 // reads costs 5 %, adding the per-wave GLOBAL weight-fragment loads costs another 20 % -- every wave of every block streams
@@ -422,20 +258,25 @@ __global__ __launch_bounds__(256, 3) void conv_dma_kernel(const ConvParams p) {
 //     ahead; the input patch of the next chunk is prefetched into registers during the MFMA loop and written to the
 //     (single, padded) LDS patch between two barriers;
 //   * the MFMA loop contains no vector-memory instruction at all: ds_read_b128 with immediate offsets, one step ahead.
-template <int KS, int DIL>
+// CK_ = input channels per chunk; WN = waves along N: the 8 waves are WM x WN, each wave MT=2 rows x 64 output channels, so a
+// block covers a (WM*2) x 32 tile and WN consecutive 64-channel output chunks.  3x3: CK 16, WN 1 (16 x 32 tile).
+// 1x1 (192 -> 120/150): CK 64, WN 2 (8 x 32 tile, both output chunks of Kp = 120 in one block: the patch is staged once).
+template <int KS, int DIL, int CK_ = 16, int WN_ = 1>
 struct Geo3 {
-    static constexpr int TH = 16, MT = 2, CK = 16, GPC = 2;
+    static constexpr int MT = 2, CK = CK_, GPC = CK_ / 8, WN = WN_, WM = 8 / WN_;
+    static constexpr int TH = WM * MT;
     static constexpr int IH = TH + (KS - 1) * DIL, IW = TW + (KS - 1) * DIL;
     static constexpr int PS = CK + 4;
     static constexpr int TAPS = KS * KS;
     static constexpr int A_FLOATS = IH * IW * PS;
-    static constexpr int B_FLOATS = TAPS * GPC * 2 * 256;          // one chunk's weight slab
+    static constexpr int BW_FLOATS = TAPS * GPC * 2 * 256;          // one chunk's weight slab for ONE 64-channel output chunk
+    static constexpr int B_FLOATS = WN * BW_FLOATS;
     static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS) * 4;
 };
 
-template <int KS, int DIL>
+template <int KS, int DIL, int CK_, int WN_>
 __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
-    using G = Geo3<KS, DIL>;
+    using G = Geo3<KS, DIL, CK_, WN_>;
     constexpr int MT = G::MT, CK = G::CK, GPC = G::GPC, NSTEPS = G::TAPS * GPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_a = lds;
@@ -443,6 +284,7 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, lx = lane & 31;
+    const int wm = wave / G::WN, wn = wave % G::WN;   // wave -> (row pair, 64-channel output chunk)
     const int n_cc = p.Cin / CK;
     const int groups_total = p.Cin / 8;
     const int tiles = p.tiles_x * p.tiles_y;
@@ -456,7 +298,8 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
     const int count = qi + (kb < ri ? 1 : 0);
     const int n_stages = count * n_cc;
 
-    constexpr int NB_DMA = G::B_FLOATS / 256;
+    constexpr int NB_DMA = G::B_FLOATS / 256, NBW = G::BW_FLOATS / 256;
+    const int n_groups_o = (p.n_chunks_o + G::WN - 1) / G::WN;
     constexpr int V = CK / 4;
     constexpr int TOTAL = G::IH * G::IW * V;
     constexpr int NIT = (TOTAL + 511) / 512;
@@ -464,12 +307,16 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
     // fetch stage s: weight slab -> LDS slab (s & 1) by DMA, input patch -> registers
     auto fetch = [&](int s_) {
         const int item = first + s_ / n_cc, cc = s_ % n_cc;
-        const int tile = item % tiles, chunk_o = (item / tiles) % p.n_chunks_o, b = item / tiles / p.n_chunks_o;
-        const float *src = p.w + ((size_t)chunk_o * groups_total * G::TAPS * 2 + (size_t)cc * GPC * G::TAPS * 2) * 256 + lane * 4;
+        const int tile = item % tiles, group_o = (item / tiles) % n_groups_o, b = item / tiles / n_groups_o;
         float *dst = lds_b + (s_ & 1) * G::B_FLOATS;
-        for (int j = wave; j < NB_DMA; j += 8)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + j * 256),
+        for (int j = wave; j < NB_DMA; j += 8) {
+            // slab part of output chunk group_o*WN + j / NBW (clamped: a partial last group re-reads the last chunk)
+            int co = group_o * G::WN + j / NBW;
+            co = co < p.n_chunks_o ? co : p.n_chunks_o - 1;
+            const float *src = p.w + ((size_t)co * groups_total * G::TAPS * 2 + (size_t)cc * GPC * G::TAPS * 2) * 256 + (j % NBW) * 256 + lane * 4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dst + j * 256), 16, 0, 0);
+        }
         const int iy0 = (tile / p.tiles_x) * G::TH - p.pad, ix0 = (tile % p.tiles_x) * TW - p.pad;
         const float *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cstride + p.in_coff + cc * CK;
 #pragma unroll
@@ -494,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
     };
 
     if (n_stages > 0) fetch(0);
-    const float *a_lane = lds_a + ((wave * MT) * G::IW + lx) * G::PS + half * 4;
+    const float *a_lane = lds_a + ((wm * MT) * G::IW + lx) * G::PS + half * 4;
     int stage = 0;
     for (int it_ = 0; it_ < count; ++it_) {
         const int item = first + it_;
@@ -512,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
             store_patch();
             __syncthreads();                                   // patch + slab of this stage visible to the whole block
             if (stage + 1 < n_stages) fetch(stage + 1);
-            const float *b_lane = lds_b + (stage & 1) * G::B_FLOATS + lane * 4;
+            const float *b_lane = lds_b + (stage & 1) * G::B_FLOATS + wn * G::BW_FLOATS + lane * 4;
             f32x4 aq[2][MT], bq[2][2];
             auto load_ab = [&](int st, f32x4 (&a)[MT], f32x4 (&bb)[2]) {
                 const int tap = st / GPC, g = st % GPC;
@@ -541,11 +388,12 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
         }
 
         // ---- epilogue of this item; its stores overlap the next item's first fetch (already in flight) ----
-        const int tile = item % tiles, chunk_o = (item / tiles) % p.n_chunks_o, b = item / tiles / p.n_chunks_o;
+        const int tile = item % tiles, chunk_o = ((item / tiles) % n_groups_o) * G::WN + wn, b = item / tiles / n_groups_o;
         const int oy0 = (tile / p.tiles_x) * G::TH, ox0 = (tile % p.tiles_x) * TW;
+        if (chunk_o >= p.n_chunks_o) continue;   // wave-uniform: this wave's output chunk does not exist (partial last group)
         // launder the lane coordinates once per item: otherwise the ~128 loop-invariant per-lane store addresses are
         // hoisted out of the item loop, live across the MFMA loop and spill
-        int e_lx = lx, e_half = half, e_wave = wave;
+        int e_lx = lx, e_half = half, e_wave = wm;
         asm volatile("" : "+v"(e_lx), "+v"(e_half), "+v"(e_wave));
         const bool relu = p.epilogue & L3C_EPI_RELU;
         const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
@@ -699,20 +547,6 @@ int launch(ConvParams &p, hipStream_t stream) {
     return l3c::check_launch("conv_mfma_kernel");
 }
 
-// 256 bytes of zeros per device, allocated on first use (the only allocation this library ever makes; it is a constant).
-const float *zero_page() {
-    static const float *pages[64] = {nullptr};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (!pages[dev]) {
-        void *ptr = nullptr;
-        if (hipMalloc(&ptr, 256) != hipSuccess) return nullptr;
-        if (hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
-        pages[dev] = static_cast<const float *>(ptr);
-    }
-    return pages[dev];
-}
-
 int num_cus() {
     static int n = 0;
     if (!n) {
@@ -724,54 +558,34 @@ int num_cus() {
     return n;
 }
 
-template <int KS, int DIL>
+template <int KS, int DIL, int CK_ = 16, int WN_ = 1>
 int launch_lds(ConvParams &p, hipStream_t stream) {
-    using G = Geo3<KS, DIL>;
+    using G = Geo3<KS, DIL, CK_, WN_>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
-    L3C_REQUIRE(p.Cin % 16 == 0, "Cin must be a multiple of 16");
+    L3C_REQUIRE(p.Cin % G::CK == 0, "Cin must be a multiple of the channel chunk");
     p.tiles_x = (p.Wout + TW - 1) / TW;
     p.tiles_y = (p.Hout + G::TH - 1) / G::TH;
     p.n_chunks_o = (p.Cout + 63) / 64;
-    const int64_t total = (int64_t)p.tiles_x * p.tiles_y * p.n_chunks_o * p.B;
+    const int64_t total = (int64_t)p.tiles_x * p.tiles_y * ((p.n_chunks_o + G::WN - 1) / G::WN) * p.B;
     L3C_REQUIRE(total < (1ll << 31), "grid too large");
     p.total_blocks = (int)total;
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in
     if (!attr_set) {
-        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lds_kernel<KS, DIL>),
+        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lds_kernel<KS, DIL, CK_, WN_>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES),
                                       "hipFuncSetAttribute");
         if (rc != L3C_OK) return rc;
         attr_set = true;
     }
-    // One work item per block: the kernel can walk a range of items (persistent, cross-item prefetch) but measured in
-    // the pipeline a static partition loses more to interference from concurrently running coder waves than the
-    // prologue bubble costs; the hardware dispatcher balances dynamically.  L3C_CONV_PERSISTENT=1 switches it back.
-    static const bool persistent = getenv("L3C_CONV_PERSISTENT") != nullptr;
-    const int64_t resident = num_cus();
-    const unsigned grid = (unsigned)((persistent && total > resident) ? resident : total);
-    hipLaunchKernelGGL((conv_lds_kernel<KS, DIL>), dim3(grid), dim3(512), G::LDS_BYTES, stream, p);
+    // Items per block: the kernel walks a contiguous range of items with cross-item prefetch (the next tile's first stage is
+    // fetched during the current tile's last chunk, its epilogue stores overlap that fetch).  A fully persistent grid
+    // (one block per CU, static partition) loses more to interference from the concurrently running coder waves than it
+    // gains; a few items per block keeps the hardware dispatcher's dynamic balancing.  L3C_CONV_ITEMS_PER_BLOCK overrides.
+    static const int items_per_block = getenv("L3C_CONV_ITEMS_PER_BLOCK") ? atoi(getenv("L3C_CONV_ITEMS_PER_BLOCK")) : 1;
+    const int ipb = items_per_block > 0 ? items_per_block : 1;
+    const unsigned grid = (unsigned)((total + ipb - 1) / ipb);
+    hipLaunchKernelGGL((conv_lds_kernel<KS, DIL, CK_, WN_>), dim3(grid), dim3(512), G::LDS_BYTES, stream, p);
     return l3c::check_launch("conv_lds_kernel");
-}
-
-template <int KS, int DIL, int MT>
-int launch_dma(ConvParams &p, hipStream_t stream) {
-    using G = Geo<KS, 1, DIL, 16, MT>;
-    constexpr int NWI = (G::IH * G::IW * 4 + 63) / 64;
-    constexpr int LDS_BYTES = 2 * NWI * 1024;
-    static_assert(LDS_BYTES <= 64 * 1024, "LDS buffers too large");
-    L3C_REQUIRE(p.Cin % 16 == 0, "Cin must be a multiple of 16");
-    p.zero_page = zero_page();
-    L3C_REQUIRE(p.zero_page != nullptr, "could not allocate the zero page");
-    p.tiles_x = (p.Wout + TW - 1) / TW;
-    p.tiles_y = (p.Hout + G::TH - 1) / G::TH;
-    p.n_chunks_o = (p.Cout + 63) / 64;
-    const int64_t items = (int64_t)p.tiles_x * p.tiles_y * p.n_chunks_o * p.B;
-    L3C_REQUIRE(items < (1ll << 31), "grid too large");
-    p.total_blocks = (int)items;
-    const int64_t resident = (int64_t)num_cus() * 3;      // 3 blocks per CU (LDS 45 KB, <= 168 VGPRs)
-    const unsigned grid = (unsigned)(items < resident ? items : resident);
-    hipLaunchKernelGGL((conv_dma_kernel<KS, DIL, MT>), dim3(grid), dim3(256), LDS_BYTES, stream, p);
-    return l3c::check_launch("conv_dma_kernel");
 }
 
 }  // namespace
@@ -803,10 +617,12 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
         const int dbg = (d->epilogue >> 8) & 3;
         return dbg == 1 ? launch<3, 1, 1, 16, 2, 1>(p, s) : dbg == 2 ? launch<3, 1, 1, 16, 2, 2>(p, s) : launch<3, 1, 1, 16, 2, 3>(p, s);
     }
-    if (d->KS == 3 && d->dilation == 1) return (d->epilogue & 2048) ? launch<3, 1, 1, 16, 2>(p, s) : ((d->epilogue & 4096) ? launch_dma<3, 1, 2>(p, s) : launch_lds<3, 1>(p, s));
+    if (d->KS == 3 && d->dilation == 1) return (d->epilogue & 2048) ? launch<3, 1, 1, 16, 2>(p, s) : launch_lds<3, 1>(p, s);
     if (d->KS == 3 && d->dilation == 2) return (d->epilogue & 2048) ? launch<3, 1, 2, 16, 2>(p, s) : launch_lds<3, 2>(p, s);
     if (d->KS == 3 && d->dilation == 4) return (d->epilogue & 2048) ? launch<3, 1, 4, 16, 2>(p, s) : launch_lds<3, 4>(p, s);
     if (d->KS == 5) return launch<5, 2, 1, 16, 1>(p, s);
+    // the 1x1 192->Kp layer: v3 (launch_lds<1, 1, 64, 2>) measures the same 70 TFLOP/s as v1 -- it is not operand-bound
+    if ((d->epilogue & 4096) && d->Cin % 64 == 0) return launch_lds<1, 1, 64, 2>(p, s);
     return launch<1, 1, 1, 32, 2>(p, s);
 }
 
