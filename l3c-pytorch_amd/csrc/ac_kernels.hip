@@ -321,8 +321,37 @@ __global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restric
             if (i < n_sym) {   // wave-uniform
                 const Row<NJ> row = ring[d];
                 ring[d] = load_row<NJ>(tab, row_stride, i + D, n_sym, top, lane);
-                const uint32_t count = l3c::decode_count(low, high, value);
                 uint32_t x;
+                const bool in_range = value >= low && value <= high;   // always true for a stream this coder produced
+                if (monotone && in_range) {
+                    // Division-free: cdf[m] <= count  <=>  t[m] = (span * cdf[m]) >> 16 <= value - low, and the scaled entries
+                    // are exactly the interval offsets of the state update (low' = low + t[x], high' = low - 1 + t[x+1]).
+                    const uint32_t range = high - low, d = value - low;
+                    Row<NJ> t;
+                    uint32_t rank = 0;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        t.e[j] = (uint32_t)(((uint64_t)range * row.e[j] + row.e[j]) >> 16);
+                        rank += (uint32_t)__popcll(__ballot(lane + 64 * j <= top && t.e[j] <= d));
+                    }
+                    x = rank ? rank - 1u : 0u;
+                    if ((int)(i & 63) == lane) packed_out = (int)x;
+                    if ((i & 63) == 63 || i == n_sym - 1) {
+                        const int64_t tt = (i & ~(int64_t)63) + lane;
+                        if (tt <= i) dst[tt] = (int16_t)packed_out;
+                    }
+                    if (i != n_sym - 1) {
+                        const uint32_t new_low = low + row_fetch<NJ>(t, x);
+                        const uint32_t new_high = (x == (uint32_t)top) ? high : low - 1u + row_fetch<NJ>(t, x + 1u);
+                        int n, m;
+                        l3c::renorm_counts(new_low, new_high, n, m, low, high);
+                        if (n >= 32) value = src.take(32);
+                        else if (n) value = (value << n) | src.take(n);
+                        if (m) value = ((value << m) ^ 0x80000000u) | src.take(m);
+                    }
+                    continue;
+                }
+                const uint32_t count = l3c::decode_count(low, high, value);
                 if (monotone) {
                     uint32_t rank = 0;
 #pragma unroll

@@ -1,15 +1,134 @@
-"""MultiscaleTester, the enc / dec side of the reference's test/multiscale_tester.py (`__init__` :160-220, `encode` :383-395,
-`decode` :397-408, `_read_img` / `_write_img` :410-434) on the MI355X path.  The bpsp evaluation driver with its result
-cache (`test_all` :236-351) is listed under "next" (SURVEY.md section 8f, item 1)."""
+"""MultiscaleTester -- the reference's test/multiscale_tester.py on the MI355X path: experiment loading (`__init__` :160-220),
+bpsp evaluation with a result cache (`test_all` / `test` / `_test` :236-351, `TestOutputCache` :67-102), the
+`--write_to_files` encode -> decode -> assert round trip with a time report (`_write_to_file` :353-381), and single-image
+`encode` / `decode` (:383-408, `_read_img` / `_write_img` :410-434).
+
+Evaluation is batched where the reference is image-by-image: crops of equal padded shape go through one forward; bpsp is
+still per image (per-image sums of the NLL maps), combined over auto-crops by area like `CropLossCombinator`."""
+import collections
+import fcntl
 import os
+import pickle
+import time
 
 import numpy as np
 import torch
 from PIL import Image
 
+from .. import auto_crop
+from ..bitcoding import part_suffix_helper
 from ..bitcoding.bitcoding import Bitcoding
 from ..blueprints.multiscale_blueprint import MultiscaleBlueprint
 from ..helpers import config_parser, paths
+
+_FILE_EXT = '.l3c'
+TestID = collections.namedtuple('TestID', ['dataset_id', 'restore_itr'])
+
+
+class TestResult(object):
+    """filename -> metric value of one test set (reference :104-121)."""
+
+    def __init__(self, metric_name='bpsp'):
+        self.metric_name = metric_name
+        self.per_img = collections.OrderedDict()
+
+    def __setitem__(self, filename, value):
+        self.per_img[filename] = float(value)
+
+    def __len__(self):
+        return len(self.per_img)
+
+    def mean(self):
+        return float(np.mean(list(self.per_img.values())))
+
+
+class TestOutputCache(object):
+    """Pickle file of {TestID: TestResult}, guarded by an inter-process file lock (reference :67-102)."""
+
+    def __init__(self, out_dir):
+        os.makedirs(out_dir, exist_ok=True)
+        self.pickle_p = os.path.join(out_dir, 'cache.pkl')
+        self.lock_p = os.path.join(out_dir, '.cache.lock')
+
+    def _locked(self, fn):
+        with open(self.lock_p, 'w') as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                return fn()
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
+
+    def _read(self):
+        if not os.path.isfile(self.pickle_p):
+            return {}
+        with open(self.pickle_p, 'rb') as f:
+            return pickle.load(f)
+
+    def __contains__(self, test_id):
+        return self._locked(lambda: test_id in self._read())
+
+    def __getitem__(self, test_id):
+        return self._locked(lambda: self._read()[test_id])
+
+    def __setitem__(self, test_id, result):
+        def write():
+            cache = self._read()
+            cache[test_id] = result
+            with open(self.pickle_p, 'wb') as f:
+                pickle.dump(cache, f)
+        self._locked(write)
+
+    def reset(self):
+        self._locked(lambda: os.path.isfile(self.pickle_p) and os.remove(self.pickle_p))
+
+
+class StackTimeLogger(object):
+    """Named wall-clock timers around device work (synchronising before and after, like test/cuda_timer.py:29-35, :107-151)."""
+
+    def __init__(self):
+        self.times = collections.OrderedDict()
+        self.last = collections.OrderedDict()
+        self._skip = False
+
+    class _Run(object):
+        def __init__(self, logger, name):
+            self.logger, self.name = logger, name
+
+        def __enter__(self):
+            torch.cuda.synchronize()
+            self.t0 = time.time()
+
+        def __exit__(self, *a):
+            torch.cuda.synchronize()
+            dt = time.time() - self.t0
+            self.logger.last[self.name] = dt
+            if not self.logger._skip:
+                self.logger.times.setdefault(self.name, []).append(dt)
+            return False
+
+    def run(self, name):
+        return self._Run(self, name)
+
+    prefix_scope = combine = run
+
+    def skip(self, flag):
+        """first image = warm-up: measured but not averaged (multiscale_tester.py:297)"""
+        logger = self
+
+        class _Skip(object):
+            def __enter__(self_):
+                logger._skip = flag
+
+            def __exit__(self_, *a):
+                logger._skip = False
+                return False
+        return _Skip()
+
+    def get_last_strs(self):
+        return ['{}: {:.5f}'.format(k, v) for k, v in self.last.items()]
+
+    def get_mean_strs(self):
+        return ['{}: {:.5f} (n={})'.format(k, float(np.mean(v)), len(v)) for k, v in self.times.items()]
 
 
 class EncodeError(Exception):
@@ -38,7 +157,133 @@ class MultiscaleTester(object):
         self.blueprint.set_eval()
         self.restore_itr, ckpt_p = paths.get_ckpt_for_itr(paths.get_ckpts_dir(experiment_dir), restore_itr)
         paths.restore({'net': self.blueprint.net}, ckpt_p, strict=True)
-        self.bc = Bitcoding(self.blueprint, compare_with_theory=bool(getattr(flags, 'compare_theory', False)))
+        self.times = StackTimeLogger()
+        self.bc = Bitcoding(self.blueprint, times=self.times if getattr(flags, 'write_to_files', None) else None,
+                            compare_with_theory=bool(getattr(flags, 'compare_theory', False)))
+        self.recursive = 0
+        if str(getattr(flags, 'recursive', '0') or '0') not in ('0',):
+            raise NotImplementedError('--recursive is only meaningful for the RGB Shared baseline (SURVEY.md section 8f)')
+        self.max_batch = int(getattr(flags, 'batch', None) or 8)
+        exp_name = os.path.basename(experiment_dir)
+        self.out_dir = os.path.join(flags.log_dir.rstrip(os.path.sep) + '_test', exp_name)
+        self.test_output_cache = TestOutputCache(self.out_dir)
+        if getattr(flags, 'reset_entire_cache', False):
+            self.test_output_cache.reset()
+
+    # ---- bpsp evaluation ------------------------------------------------------------------------------------------------
+
+    def _padding_fac(self):
+        return 2 ** self.config_ms.num_scales
+
+    def test_all(self, testsets):
+        results = [self.test(testset) for testset in testsets]
+        if getattr(self.flags, 'write_to_files', None):
+            return [None]
+        return [(testset, self.log_date, self.restore_itr, '{}={}'.format(r.metric_name, r.mean()))
+                for testset, r in zip(testsets, results)]
+
+    def test(self, testset):
+        test_id = TestID(testset.id, self.restore_itr)
+        write = getattr(self.flags, 'write_to_files', None)
+        if not getattr(self.flags, 'overwrite_cache', False) and not write and test_id in self.test_output_cache:
+            print('*** Found cached: {}'.format(test_id))
+            return self.test_output_cache[test_id]
+        print('Testing {}'.format(testset))
+        with torch.no_grad():
+            result = self._test_write(testset) if write else self._test(testset)
+        if write:
+            return None
+        self.test_output_cache[test_id] = result
+        return result
+
+    def _load_uint8(self, img_p):
+        img = Image.open(img_p)
+        crop = getattr(self.flags, 'crop', None)
+        if crop:
+            w, h = img.size
+            l, t = (w - crop) // 2, (h - crop) // 2
+            img = img.crop((l, t, l + crop, t + crop))
+        arr = np.array(img)
+        if arr.ndim == 2:
+            arr = np.stack([arr] * 3, axis=-1)
+        return torch.from_numpy(np.ascontiguousarray(arr[..., :3].transpose(2, 0, 1)))
+
+    def per_image_bpsp(self, out, num_subpixels_before_pad):
+        """(B,) bpsp of a forward: per-image sums of the NLL maps + the uniform cost of the coarsest scale
+        (multiscale_network.Losses.get :145-165, blueprint.get_loss :64-95, evaluated per batch item)."""
+        losses = self.blueprint.losses
+        nats = losses.loss_dmol_rgb(out.S[0].float(), out.P[0]).sum(dim=(1, 2, 3))
+        for s in range(1, len(out.P)):
+            nats = nats + losses.loss_dmol_n(out.bn[s], out.P[s]).sum(dim=(1, 2, 3))
+        _, C, H, W = out.S[-1].shape
+        nats = nats + C * H * W * float(np.log(out.L[-1]))
+        conv = torch.tensor([np.log(2.) * n for n in num_subpixels_before_pad], dtype=torch.float64, device=nats.device)
+        return (nats.double() / conv).cpu().numpy()
+
+    def _test(self, testset):
+        test_result = TestResult('bpsp')
+        # every auto-crop of every image, grouped by padded shape so that equal shapes share one forward
+        items, groups = [], collections.defaultdict(list)
+        for i, img_p in enumerate(testset.ps):
+            raw = self._load_uint8(img_p).unsqueeze(0)
+            for crop in auto_crop.iter_crops(raw):
+                n_sub = int(np.prod(crop.shape))
+                padded = MultiscaleBlueprint.pad(crop, self._padding_fac())
+                groups[tuple(padded.shape[-2:])].append(len(items))
+                items.append({'img': i, 'n_sub': n_sub, 'padded': padded, 'bpsp': None})
+        for shape, idxs in groups.items():
+            for k in range(0, len(idxs), self.max_batch):
+                chunk = idxs[k:k + self.max_batch]
+                batch = torch.cat([items[j]['padded'] for j in chunk], dim=0).to('cuda', torch.float32)
+                out = self.blueprint.forward(batch)
+                bpsp = self.per_image_bpsp(out, [items[j]['n_sub'] for j in chunk])
+                for j, b in zip(chunk, bpsp):
+                    items[j]['bpsp'] = float(b)
+        for i, img_p in enumerate(testset.ps):
+            comb = auto_crop.CropLossCombinator()
+            for it in items:
+                if it['img'] == i:
+                    comb.add(it['bpsp'], it['n_sub'])
+            filename = os.path.splitext(os.path.basename(img_p))[0]
+            test_result[filename] = comb.get_bpsp()
+            print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+        return test_result
+
+    # ---- --write_to_files: real files, real round trip ---------------------------------------------------------------------
+
+    def _test_write(self, testset):
+        test_result = TestResult('bpsp')
+        out_dir = self.flags.write_to_files
+        os.makedirs(out_dir, exist_ok=True)
+        for i, img_p in enumerate(testset.ps):
+            filename = os.path.splitext(os.path.basename(img_p))[0]
+            print('***', filename)
+            img = self._load_uint8(img_p).unsqueeze(0).long()
+            with self.times.skip(i == 0):
+                test_result[filename] = self._write_to_file(img, os.path.join(out_dir, filename + _FILE_EXT))
+            print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+        return test_result
+
+    def _write_to_file(self, img, out_p):
+        for stale in [out_p] + ([p for p in part_suffix_helper.iter_part_suffixes(out_p + '.part0')]
+                                if os.path.isfile(out_p + '.part0') else []):
+            if os.path.isfile(stale):
+                os.remove(stale)
+        with self.times.run('=== bc.encode'):
+            bpsp = self.bc.encode(img, pout=out_p)
+        out_p_part = out_p + part_suffix_helper.make_part_suffix(0)
+        if not os.path.isfile(out_p) and os.path.isfile(out_p_part):
+            out_p = out_p_part
+        with self.times.run('=== bc.decode'):
+            img_o = self.bc.decode(pin=out_p)
+        if not torch.equal(img_o.cpu(), img.cpu()):
+            raise AssertionError('decoded image differs from the input: {}'.format(out_p))
+        print('\n'.join(self.times.get_last_strs()))
+        if getattr(self.flags, 'time_report', None):
+            with open(self.flags.time_report, 'w') as f:
+                f.write('Average times:\n')
+                f.write('\n'.join(self.times.get_mean_strs()))
+        return bpsp
 
     def encode(self, img_p, pout, overwrite=False):
         pout_dir = os.path.dirname(os.path.abspath(pout))

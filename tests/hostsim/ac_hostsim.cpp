@@ -62,7 +62,28 @@ void hostsim_decode(const uint16_t *cdf, long long row_stride, int Lp, const uin
         const uint16_t *row = cdf + i * row_stride;
         const uint32_t count = l3c::decode_count(low, high, value);
         uint32_t x;
-        if (monotone) {  // what the wavefront does: rank of `count` among the valid entries (ballot + popcount)
+        if (monotone == 2 && value >= low && value <= high) {
+            // division-free rank (ac_decode_kernel fast path): cdf[m] <= count  <=>  (span * cdf[m]) >> 16 <= value - low
+            const uint32_t range = high - low, d = value - low;
+            uint32_t rank = 0;
+            for (uint32_t m = 0; m <= top; ++m) rank += (uint32_t)(((uint64_t)range * row[m] + row[m]) >> 16) <= d;
+            x = rank ? rank - 1 : 0;
+            sym_out[i] = (int16_t)x;
+            if (i == N - 1) break;
+            // the scaled entries ARE the interval offsets: low' = low + t[x], high' = low - 1 + t[x+1] (top symbol: high)
+            const uint32_t t_lo = (uint32_t)(((uint64_t)range * row[x] + row[x]) >> 16);
+            const uint32_t new_high = x == top ? high : low - 1u + (uint32_t)(((uint64_t)range * row[x + 1] + row[x + 1]) >> 16);
+            const uint32_t new_low = low + t_lo;
+            int n, m2;
+            uint32_t nl, nh;
+            l3c::renorm_counts(new_low, new_high, n, m2, nl, nh);
+            if (n >= 32) value = src.take(32);
+            else if (n) value = (value << n) | src.take(n);
+            if (m2) value = ((value << m2) ^ 0x80000000u) | src.take(m2);
+            low = nl;
+            high = nh;
+            continue;
+        } else if (monotone) {  // what the wavefront does: rank of `count` among the valid entries (ballot + popcount)
             uint32_t rank = 0;
             for (uint32_t m = 0; m <= top; ++m) rank += row[m] <= count;
             x = rank ? rank - 1 : 0;

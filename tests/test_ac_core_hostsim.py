@@ -19,6 +19,7 @@ def test_hostsim_kats(golden):
         assert hs.encode(tab, sym, fast=3) == ref, n
         assert hs.encode(tab, sym, fast=False) == ref, n
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), n
+        assert (hs.decode(tab, ref, len(sym), 2) == sym).all(), n
         assert (hs.decode(tab, ref, len(sym), False) == sym).all(), n
 
 
@@ -45,6 +46,14 @@ def _random_case(rng, it):
     return tab, sym
 
 
+_last_junk = [b'']
+
+
+def junk_probe(rng):
+    _last_junk[0] = rng.randint(0, 256, size=rng.randint(0, 200)).astype(np.uint8).tobytes()
+    return _last_junk[0]
+
+
 def test_hostsim_random_vs_oracle():
     rng = np.random.RandomState(0)
     for it in range(120):
@@ -55,6 +64,8 @@ def test_hostsim_random_vs_oracle():
         assert hs.encode(tab, sym, fast=3) == ref, it
         assert hs.encode(tab, sym, fast=False) == ref, it
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), it
+        assert (hs.decode(tab, ref, len(sym), 2) == sym).all(), it
+        assert (hs.decode(tab, junk_probe(rng), len(sym), 2) == ac.decode(tab, _last_junk[0])).all(), ('junk2', it)
         assert (hs.decode(tab, ref, len(sym), False) == sym).all(), it
         junk = rng.randint(0, 256, size=rng.randint(0, 200)).astype(np.uint8).tobytes()
         assert (hs.decode(tab, junk, len(sym), False) == ac.decode(tab, junk)).all(), ('junk', it)

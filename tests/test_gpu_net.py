@@ -186,3 +186,46 @@ def test_l3c_cli_enc_dec_roundtrip(synthetic_l3c, tmp_path):
     assert cli.main([str(tmp_path / 'logs'), '0306_0001', 'dec', out, png]) == 0
     back = torch.from_numpy(np.array(Image.open(png))).permute(2, 0, 1)
     assert torch.equal(back, img)
+
+
+def test_test_py_driver_bpsp_cache_and_write_to_files(synthetic_l3c, tmp_path, capsys):
+    """`python test.py LOG_DIR LOG_DATE IMAGES [--write_to_files D --time_report P]` (reference test.py:44-137): per-image bpsp
+    equals the oracle's get_loss within 1e-4 relative, the result cache answers the second run, --write_to_files round-trips."""
+    import importlib.util
+    from PIL import Image
+    from l3c_pytorch_amd.helpers import synthetic
+    cfg, sd = synthetic_l3c
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exp = tmp_path / 'logs' / '0306_0001 cr oi' / 'ckpts'
+    exp.mkdir(parents=True)
+    torch.save({'net': sd}, str(exp / 'ckpt_0000000001.pt'))
+    imgs_dir = tmp_path / 'imgs'
+    imgs_dir.mkdir()
+    imgs = {}
+    for name, (H, W) in {'a': (32, 48), 'b': (32, 48), 'c': (27, 41)}.items():
+        imgs[name] = synthetic.make_image(H, W, ord(name), 'natural')
+        Image.fromarray(imgs[name].permute(1, 2, 0).numpy()).save(str(imgs_dir / (name + '.png')))
+    spec = importlib.util.spec_from_file_location('l3c_test_cli', os.path.join(root, 'test.py'))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    res = cli.main([str(tmp_path / 'logs'), '0306_0001', str(imgs_dir)])
+    (testset, log_date, itr, result), = res
+    assert testset.id == 'imgs_3' and log_date == '0306_0001' and itr == 1 and result.startswith('bpsp=')
+    # oracle per image (pad like the tester does, bpsp over the unpadded sub-pixel count)
+    from l3c_pytorch_amd.helpers import pad as padmod
+    expect = []
+    for name in 'abc':
+        x = imgs[name].unsqueeze(0)
+        xp, _ = padmod.pad(x, 8, mode='constant')
+        with torch.no_grad():
+            o = onet.forward(xp.float(), sd)
+        expect.append(sum(obc.losses_bpsp(o, num_subpixels=x.numel())))
+    assert abs(float(result.split('=')[1]) - np.mean(expect)) < 1e-4 * np.mean(expect)
+    capsys.readouterr()
+    cli.main([str(tmp_path / 'logs'), '0306_0001', str(imgs_dir)])
+    assert 'Found cached' in capsys.readouterr().out
+    out_dir = tmp_path / 'written'
+    report = tmp_path / 'times.txt'
+    cli.main([str(tmp_path / 'logs'), '0306_0001', str(imgs_dir), '--write_to_files', str(out_dir), '--time_report', str(report)])
+    assert sorted(os.listdir(str(out_dir))) == ['a.l3c', 'b.l3c', 'c.l3c']
+    assert 'bc.encode' in report.read_text() and 'bc.decode' in report.read_text()
