@@ -78,14 +78,15 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL; one process per GPU
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus {} != WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
 
     cfg, sd, bp, bc, synthetic = build_path(device, args.coder_cus)
     from l3c_pytorch_amd import _lib, ops

@@ -204,6 +204,25 @@ int l3c_to_q_quantize(const float *feat, const float *w, const float *b, const f
 int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float *fuse, int64_t B, int64_t HW, int C,
                  int Cf, float *out, l3c_stream_t stream);
 
+/*
+ * RGB baselines (BicubicSubsampling encoder, modules/net.py:65-80): the reference leaves the GPU for PIL's BICUBIC resize
+ * (dataloaders/images_loader.py:277-288).  Here the pyramid stays on the device and is bit-exact with Pillow:
+ *   l3c_meanshift_planar  1x1 conv 3->3 on a planar image (sub_rgb_mean, multiscale_network.py:241); w [3][3], b [3] on device
+ *   l3c_rgb_to_u8         uint8(round(clamp(x + mean, 0, 255)))                      planar fp32 [B][3][HW] -> uint8
+ *   l3c_resample_u8       ONE pass of Pillow's ImagingResample (8 bpc, 22-bit fixed point) along W (axis 0) or H (axis 1);
+ *                         bounds int32 [out_size][2] = (first, count), kk int32 [out_size][ksize], both on the device,
+ *                         computed on the host exactly as Pillow does (helpers/pil_resample.py)
+ *   l3c_u8_to_sym_bn      symbols (int16) = pixel values, bn = value - mean
+ * `mean3_host` is a HOST pointer to the three channel means (0.4488, 0.4371, 0.4040) * 255 as fp32.
+ */
+int l3c_meanshift_planar(const float *img, const float *w, const float *b, int64_t B, int64_t HW, float *out,
+                         l3c_stream_t stream);
+int l3c_rgb_to_u8(const float *x, const float *mean3_host, int64_t B, int64_t HW, uint8_t *out, l3c_stream_t stream);
+int l3c_resample_u8(const uint8_t *in, int64_t planes, int H, int W, int axis, int out_size, const int32_t *bounds,
+                    const int32_t *kk, int ksize, uint8_t *out, l3c_stream_t stream);
+int l3c_u8_to_sym_bn(const uint8_t *in, const float *mean3_host, int64_t B, int64_t HW, int16_t *sym, float *bn,
+                     l3c_stream_t stream);
+
 /* symbols -> bottleneck values, to_bn (quantizer.py:44-47): float(S) * bin + x_min, two separately rounded fp32 ops. */
 int l3c_sym_to_bn(const int16_t *sym, int64_t n, float bin_width, float x_min, float *bn, l3c_stream_t stream);
 

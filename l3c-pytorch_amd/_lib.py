@@ -56,6 +56,10 @@ PROTOTYPES = {
     'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'l3c_to_q_quantize': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'l3c_dec_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
+    'l3c_meanshift_planar': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    'l3c_rgb_to_u8': (c_int, [c_vp, ctypes.POINTER(c_f32), c_i64, c_i64, c_vp, c_vp]),
+    'l3c_resample_u8': (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
+    'l3c_u8_to_sym_bn': (c_int, [c_vp, ctypes.POINTER(c_f32), c_i64, c_i64, c_vp, c_vp, c_vp]),
     'l3c_sym_to_bn': (c_int, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp]),
 }
 

@@ -4,6 +4,8 @@
 //   to_q_quantize_kernel conv1x1 Cf->C + hard quantiser                          (net.py:144-148, quantizer.py:72-87)
 //   dec_head_kernel      conv1x1 C->Cf (+ fused coarser features)                (net.py:178-180)
 //   sym_to_bn_kernel     to_bn                                                   (quantizer.py:44-47)
+//   meanshift_planar / to_u8 / resample_u8 / u8_to_sym_bn   the RGB baselines' bicubic pyramid encoder, Pillow-exact
+//                        (net.py:65-80, images_loader.py:277-288; coefficient tables from helpers/pil_resample.py)
 // Wide tensors are pixel-major: 16 consecutive lanes own the 64 channels of one pixel as float4s, so a wavefront
 // reads/writes 4 pixels x 256 B = 1 KB contiguous per instruction.
 #include "l3c_common.h"
@@ -146,6 +148,71 @@ __global__ __launch_bounds__(256) void sym_to_bn_kernel(const int16_t *__restric
         bn[i] = (float)sym[i] * bin_width + x_min;   // two roundings (file is built with -ffp-contract=off)
 }
 
+// ---- RGB baselines: bicubic pyramid encoder (modules/net.py:72-80, dataloaders/images_loader.py:277-288) ------------------------
+
+__global__ __launch_bounds__(256) void meanshift_planar_kernel(const float *__restrict__ img, const float *__restrict__ w,
+                                                               const float *__restrict__ b, int64_t B, int64_t HW,
+                                                               float *__restrict__ out) {
+    const int64_t total = B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t bi = i / HW, n = i % HW;
+        const float *px = img + bi * 3 * HW + n;
+        const float v0 = px[0], v1 = px[HW], v2 = px[2 * HW];
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+            out[(bi * 3 + o) * HW + n] = ((v0 * w[o * 3 + 0] + v1 * w[o * 3 + 1]) + v2 * w[o * 3 + 2]) + b[o];
+    }
+}
+
+// x + mean -> clamp(0, 255) -> round half to even -> uint8   (net.py:73-74)
+__global__ __launch_bounds__(256) void to_u8_kernel(const float *__restrict__ x, float m0, float m1, float m2, int64_t B,
+                                                    int64_t HW, uint8_t *__restrict__ out) {
+    const int64_t total = B * 3 * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % 3);
+        const float v = x[i] + (c == 0 ? m0 : c == 1 ? m1 : m2);
+        out[i] = (uint8_t)rintf(fminf(fmaxf(v, 0.0f), 255.0f));
+    }
+}
+
+// One pass of Pillow's ImagingResample for 8-bit data (Resample.c: ImagingResampleHorizontal_8bpc / Vertical_8bpc):
+// out = clip8((2^21 + sum_k in[xmin + k] * kk[k]) >> 22).  `planes` images of H x W, resampled along W (axis 0) or H (axis 1).
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t *__restrict__ in, int64_t planes, int H, int W, int axis,
+                                                          int out_size, const int *__restrict__ bounds,
+                                                          const int *__restrict__ kk, int ksize, uint8_t *__restrict__ out) {
+    const int oh = axis ? out_size : H, ow = axis ? W : out_size;
+    const int64_t total = planes * oh * ow;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % ow), oy = (int)((i / ow) % oh);
+        const int64_t pl = i / ow / oh;
+        const int o = axis ? oy : ox;
+        const int first = bounds[o * 2], count = bounds[o * 2 + 1];
+        const int *k = kk + (int64_t)o * ksize;
+        const uint8_t *src = in + pl * H * W;
+        int acc = 1 << 21;
+        if (axis) {
+            for (int t = 0; t < count; ++t) acc += (int)src[(int64_t)(first + t) * W + ox] * k[t];
+        } else {
+            for (int t = 0; t < count; ++t) acc += (int)src[(int64_t)oy * W + first + t] * k[t];
+        }
+        acc >>= 22;   // arithmetic shift, then clip8
+        out[i] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+    }
+}
+
+// symbols = pixel values (L = 256), bn = value - mean   (net.py:76-80)
+__global__ __launch_bounds__(256) void u8_to_sym_bn_kernel(const uint8_t *__restrict__ in, float m0, float m1, float m2,
+                                                           int64_t B, int64_t HW, int16_t *__restrict__ sym,
+                                                           float *__restrict__ bn) {
+    const int64_t total = B * 3 * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((i / HW) % 3);
+        const int v = in[i];
+        sym[i] = (int16_t)v;
+        bn[i] = (float)v - (c == 0 ? m0 : c == 1 ? m1 : m2);
+    }
+}
+
 int grid_1d(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
@@ -183,6 +250,39 @@ int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float 
     hipLaunchKernelGGL(dec_head_kernel, dim3(grid_1d(B * HW * (Cf / 4), 256)), dim3(256), 0, l3c::as_stream(stream), bn_q,
                        w, b, fuse, B, HW, C, Cf, out);
     return l3c::check_launch("dec_head_kernel");
+}
+
+int l3c_meanshift_planar(const float *img, const float *w, const float *b, int64_t B, int64_t HW, float *out,
+                         l3c_stream_t stream) {
+    L3C_REQUIRE(img && w && b && out && B > 0 && HW > 0, "bad arguments");
+    hipLaunchKernelGGL(meanshift_planar_kernel, dim3(grid_1d(B * HW, 256)), dim3(256), 0, l3c::as_stream(stream), img, w, b, B,
+                       HW, out);
+    return l3c::check_launch("meanshift_planar_kernel");
+}
+
+int l3c_rgb_to_u8(const float *x, const float *mean3_host, int64_t B, int64_t HW, uint8_t *out, l3c_stream_t stream) {
+    L3C_REQUIRE(x && mean3_host && out && B > 0 && HW > 0, "bad arguments");
+    hipLaunchKernelGGL(to_u8_kernel, dim3(grid_1d(B * 3 * HW, 256)), dim3(256), 0, l3c::as_stream(stream), x, mean3_host[0],
+                       mean3_host[1], mean3_host[2], B, HW, out);
+    return l3c::check_launch("to_u8_kernel");
+}
+
+int l3c_resample_u8(const uint8_t *in, int64_t planes, int H, int W, int axis, int out_size, const int32_t *bounds,
+                    const int32_t *kk, int ksize, uint8_t *out, l3c_stream_t stream) {
+    L3C_REQUIRE(in && bounds && kk && out, "null pointer");
+    L3C_REQUIRE(planes > 0 && H > 0 && W > 0 && out_size > 0 && ksize > 0 && (axis == 0 || axis == 1), "bad shape");
+    const int64_t total = planes * (axis ? (int64_t)out_size * W : (int64_t)H * out_size);
+    hipLaunchKernelGGL(resample_u8_kernel, dim3(grid_1d(total, 256)), dim3(256), 0, l3c::as_stream(stream), in, planes, H, W,
+                       axis, out_size, bounds, kk, ksize, out);
+    return l3c::check_launch("resample_u8_kernel");
+}
+
+int l3c_u8_to_sym_bn(const uint8_t *in, const float *mean3_host, int64_t B, int64_t HW, int16_t *sym, float *bn,
+                     l3c_stream_t stream) {
+    L3C_REQUIRE(in && mean3_host && sym && bn && B > 0 && HW > 0, "bad arguments");
+    hipLaunchKernelGGL(u8_to_sym_bn_kernel, dim3(grid_1d(B * 3 * HW, 256)), dim3(256), 0, l3c::as_stream(stream), in,
+                       mean3_host[0], mean3_host[1], mean3_host[2], B, HW, sym, bn);
+    return l3c::check_launch("u8_to_sym_bn_kernel");
 }
 
 int l3c_sym_to_bn(const int16_t *sym, int64_t n, float bin_width, float x_min, float *bn, l3c_stream_t stream) {

@@ -8,7 +8,8 @@ csrc/ (MFMA implicit GEMM + the small fused kernels), driven layer by layer in t
 Inference only (the reference's eval mode): decoders are fed the quantised bottleneck (`bn_q`), `Out.bn[i]` is `bn_q`.
 Internally every wide activation is pixel-major (NHWC); tensors handed out through the reference API keep the reference's
 logical NCHW shape (P as a zero-copy permuted view, symbols / bottlenecks planar).
-Only the L3C family (EDSRLikeEnc/EDSRDec) is on this path; the RGB baselines (BicubicSubsampling) raise.
+Both model families of the reference are covered: L3C (EDSRLikeEnc/EDSRDec, configs/ms/cr.cf) and the RGB / RGB Shared
+baselines (BicubicSubsampling, cr_rgb.cf / cr_rgb_shared.cf, forward + loss like the reference: it has no file coding for them).
 """
 import itertools
 
@@ -120,17 +121,20 @@ def _build_param_tree(root, shapes):
 class MultiscaleNetwork(nn.Module):
     def __init__(self, config_ms):
         super(MultiscaleNetwork, self).__init__()
-        if config_ms.rgb_bicubic_baseline or config_ms.enc.cls != 'EDSRLikeEnc' or config_ms.dec.cls != 'EDSRDec':
-            raise NotImplementedError('only the L3C family (EDSRLikeEnc / EDSRDec) is on the MI355X hot path; the RGB '
-                                      'baselines (BicubicSubsampling) are listed as "next" in SURVEY.md section 8f')
-        if not (config_ms.enc.feed_F and config_ms.dec.skip):
-            raise NotImplementedError('enc.feed_F and dec.skip are assumed True (configs/ms/cr.cf)')
+        self._rgb = bool(config_ms.rgb_bicubic_baseline)
+        if config_ms.dec.cls != 'EDSRDec':
+            raise NotImplementedError('decoder class {}'.format(config_ms.dec.cls))
+        if self._rgb:
+            # RGB / RGB Shared baselines: bicubic pyramid instead of learned encoders, every scale predicts RGB symbols
+            if config_ms.enc.cls != 'BicubicSubsampling' or config_ms.enc.feed_F or config_ms.q.C != 3:
+                raise NotImplementedError('RGB baselines need enc.cls=BicubicSubsampling, enc.feed_F=False, q.C=3')
+        elif config_ms.enc.cls != 'EDSRLikeEnc' or not (config_ms.enc.feed_F and config_ms.dec.skip):
+            raise NotImplementedError('L3C needs enc.cls=EDSRLikeEnc, enc.feed_F and dec.skip (configs/ms/cr.cf)')
         if config_ms.Cf % 32 != 0 or config_ms.kernel_size != 3:
             raise NotImplementedError('Cf must be a multiple of 32 and kernel_size 3')
         self.config_ms = config_ms
         self.scales = config_ms.num_scales
-        self._rgb = False
-        self._fuse_feat = True
+        self._fuse_feat = bool(config_ms.dec.skip)
         self._schema = schema.param_schema(config_ms)
         _build_param_tree(self, self._schema)
         self._packed = None
@@ -155,7 +159,7 @@ class MultiscaleNetwork(nn.Module):
             return self._packed
         sd = {k: v.detach() for k, v in self.state_dict().items()}
         cfg = self.config_ms
-        lv = schema_levels_check(sd, cfg)
+        lv = True if self._rgb else schema_levels_check(sd, cfg)
         dev = lambda t: t.to('cuda', torch.float32).contiguous()   # noqa: E731
         pk = {'levels_ok': lv}
 
@@ -167,16 +171,18 @@ class MultiscaleNetwork(nn.Module):
             return blocks, pc('{}.{}'.format(prefix, n))
 
         pk['ms1'] = (dev(sd['sub_rgb_mean.weight'].reshape(3, 3)), dev(sd['sub_rgb_mean.bias']))
-        pk['ms2'] = (dev(sd['heads.0.head.0.weight'].reshape(3, 3)), dev(sd['heads.0.head.0.bias']))
-        pk['head0'] = (dev(sd['heads.0.head.1.head.weight']), dev(sd['heads.0.head.1.head.bias']))
-        pk['heads'] = [None] + [pc('heads.{}.head'.format(s)) for s in range(1, self.scales)]
+        if not self._rgb:
+            pk['ms2'] = (dev(sd['heads.0.head.0.weight'].reshape(3, 3)), dev(sd['heads.0.head.0.bias']))
+            pk['head0'] = (dev(sd['heads.0.head.1.head.weight']), dev(sd['heads.0.head.1.head.bias']))
+            pk['heads'] = [None] + [pc('heads.{}.head'.format(s)) for s in range(1, self.scales)]
         pk['enc'], pk['dec'], pk['prob'] = [], [], []
         for s in range(self.scales):
             e, d = 'nets.{}.enc'.format(s), 'nets.{}.dec'.format(s)
-            eb, et = body(e + '.body', cfg.enc.num_blocks)
-            pk['enc'].append({'down': pc(e + '.down', stride=2), 'blocks': eb, 'tail': et,
-                              'to_q': (dev(sd[e + '.to_q.0.weight'].reshape(cfg.q.C, cfg.Cf)), dev(sd[e + '.to_q.0.bias'])),
-                              'levels': dev(sd[e + '.levels'])})
+            if not self._rgb:
+                eb, et = body(e + '.body', cfg.enc.num_blocks)
+                pk['enc'].append({'down': pc(e + '.down', stride=2), 'blocks': eb, 'tail': et,
+                                  'to_q': (dev(sd[e + '.to_q.0.weight'].reshape(cfg.q.C, cfg.Cf)), dev(sd[e + '.to_q.0.bias'])),
+                                  'levels': dev(sd[e + '.levels'])})
             db, dt = body(d + '.body', cfg.dec.num_blocks)
             pk['dec'].append({'head': (dev(sd[d + '.head.weight'].reshape(cfg.Cf, cfg.q.C)), dev(sd[d + '.head.bias'])),
                               'blocks': db, 'tail': dt, 'up': pc(d + '.tail.0')})
@@ -221,12 +227,15 @@ class MultiscaleNetwork(nn.Module):
     # -- reference API --------------------------------------------------------------------------------------------------
 
     def forward(self, x, auto_recurse=0):
-        """x: image NCHW in [0, 255] (float) -> Out."""
-        if auto_recurse:
-            raise NotImplementedError('auto_recurse is only used by the RGB Shared baseline')
+        """x: image NCHW in [0, 255] (float) -> Out.  auto_recurse: how many times the coarsest scale is applied again (the RGB
+        Shared baseline is evaluated with auto_recurse=3, multiscale_tester.py:50, :123-132)."""
         _lib.require_gpu()
         x = self._as_device_image(x)
         pk = self._prepare()
+        if self._rgb:
+            return self._forward_rgb(x, auto_recurse, pk)
+        if auto_recurse:
+            raise NotImplementedError('auto_recurse is only used by the RGB Shared baseline')
         out = Out(targets_style='bn', auto_recursive_from=None)
         out.append_input_image(x)
         raw = out.raw
@@ -252,6 +261,35 @@ class MultiscaleNetwork(nn.Module):
             raw.F_enc.append(F)
             raw.F_dec.append(dec[s])
             out.append(EncOut(bn_q, bn_q, sym.long(), self.config_ms.q.L, F.permute(0, 3, 1, 2)), P.permute(0, 3, 1, 2))
+        return out
+
+    def _forward_rgb(self, x, auto_recurse, pk):
+        """RGB baselines (reference :226-306 with rgb_bicubic_baseline): identity heads, bicubic pyramid encoders
+        (Pillow-exact, on the device), the scale's decoder + classifier predict the RGB symbols of the finer scale."""
+        forward_scales = list(range(self.scales)) + [-1] * auto_recurse
+        out = Out(targets_style='S', auto_recursive_from=self.scales if auto_recurse > 0 else None)
+        out.append_input_image(x)
+        raw = out.raw
+        raw.sym.append(out.S[0].to(torch.int16))
+        raw.bn_q.append(None)
+        inp = ops.meanshift_planar(x, pk['ms1'][0], pk['ms1'][1])
+        encs = []
+        for _ in forward_scales:
+            bn, sym = ops.bicubic_encoder(inp)
+            encs.append((bn, sym))
+            inp = bn                                     # enc.feed_F is False: the next scale sees the subsampled image
+        decs = []
+        for i, s in reversed(list(enumerate(forward_scales))):
+            fuse = None if (not self._fuse_feat or s == -1 or s == max(forward_scales)) else decs[0]
+            decs.insert(0, self._decoder(encs[i][0], fuse, s if s >= 0 else self.scales - 1, pk))
+        for i, s in enumerate(forward_scales):
+            bn, sym = encs[i]
+            P = self._prob(decs[i], s if s >= 0 else self.scales - 1, pk)
+            raw.sym.append(sym)
+            raw.bn_q.append(bn)
+            raw.P.append(P)
+            raw.F_dec.append(decs[i])
+            out.append(EncOut(bn, bn, sym.long(), 256, None), P.permute(0, 3, 1, 2))
         return out
 
     def get_P(self, scale, bn_q, dec_F_prev=None):

@@ -1,5 +1,6 @@
 """Tensor-level wrappers of the HIP entry points (include/l3c_hip.h).  torch is only the owner of device memory and of
 the current stream here; every function enqueues kernels from libl3c_hip.so and nothing else."""
+import ctypes
 import os
 
 import torch
@@ -108,6 +109,58 @@ def sym_to_bn(sym, bin_width, x_min):
     bn = torch.empty(sym.shape, dtype=torch.float32, device=sym.device)
     call('l3c_sym_to_bn', ptr(sym, torch.int16), sym.numel(), float(bin_width), float(x_min), ptr(bn), stream())
     return bn
+
+
+# ---- RGB baselines: bicubic pyramid encoder ------------------------------------------------------------------------------
+
+_RGB_MEAN = None
+_COEFFS = {}
+
+
+def rgb_mean():
+    """(0.4488, 0.4371, 0.4040) * 255 in fp32, as BicubicDownsamplingEnc builds it (net.py:69-70)."""
+    global _RGB_MEAN
+    if _RGB_MEAN is None:
+        m = torch.tensor([0.4488, 0.4371, 0.4040], dtype=torch.float32).mul(255.)
+        _RGB_MEAN = (ctypes.c_float * 3)(*[float(v) for v in m])
+    return _RGB_MEAN
+
+
+def _resample_tables(in_size, out_size, device):
+    key = (in_size, out_size, str(device))
+    if key not in _COEFFS:
+        from .helpers import pil_resample
+        bounds, kk, ksize = pil_resample.precompute_coeffs(in_size, out_size)
+        _COEFFS[key] = (torch.from_numpy(bounds).to(device), torch.from_numpy(kk).to(device), ksize)
+    return _COEFFS[key]
+
+
+def meanshift_planar(img, w, b):
+    B, _, H, W = img.shape
+    out = torch.empty_like(img)
+    call('l3c_meanshift_planar', ptr(img, torch.float32), ptr(w), ptr(b), B, H * W, ptr(out), stream())
+    return out
+
+
+def bicubic_encoder(x):
+    """x (B,3,H,W) fp32 planar, mean-shifted -> (bn (B,3,H/2,W/2) fp32, sym int16): round to uint8, Pillow-exact BICUBIC
+    half-size resize (horizontal pass, then vertical), symbols = pixel values, bn = value - mean."""
+    B, _, H, W = x.shape
+    oh, ow = int(H * 0.5), int(W * 0.5)
+    if oh < 1 or ow < 1:
+        raise ValueError('image too small for another bicubic scale: {}x{}'.format(H, W))
+    u8 = torch.empty(B, 3, H, W, dtype=torch.uint8, device=x.device)
+    call('l3c_rgb_to_u8', ptr(x, torch.float32), rgb_mean(), B, H * W, ptr(u8), stream())
+    bw, kw, ksw = _resample_tables(W, ow, x.device)
+    tmp = torch.empty(B, 3, H, ow, dtype=torch.uint8, device=x.device)
+    call('l3c_resample_u8', ptr(u8), B * 3, H, W, 0, ow, ptr(bw), ptr(kw), ksw, ptr(tmp), stream())
+    bh, kh, ksh = _resample_tables(H, oh, x.device)
+    down = torch.empty(B, 3, oh, ow, dtype=torch.uint8, device=x.device)
+    call('l3c_resample_u8', ptr(tmp), B * 3, H, ow, 1, oh, ptr(bh), ptr(kh), ksh, ptr(down), stream())
+    sym = torch.empty(B, 3, oh, ow, dtype=torch.int16, device=x.device)
+    bn = torch.empty(B, 3, oh, ow, dtype=torch.float32, device=x.device)
+    call('l3c_u8_to_sym_bn', ptr(down), rgb_mean(), B, oh * ow, ptr(sym), ptr(bn), stream())
+    return bn, sym
 
 
 # ---- logistic-mixture head --------------------------------------------------------------------------------------------

@@ -160,9 +160,9 @@ class MultiscaleTester(object):
         self.times = StackTimeLogger()
         self.bc = Bitcoding(self.blueprint, times=self.times if getattr(flags, 'write_to_files', None) else None,
                             compare_with_theory=bool(getattr(flags, 'compare_theory', False)))
-        self.recursive = 0
-        if str(getattr(flags, 'recursive', '0') or '0') not in ('0',):
-            raise NotImplementedError('--recursive is only meaningful for the RGB Shared baseline (SURVEY.md section 8f)')
+        self.recursive = self._parse_recursive_flag(getattr(flags, 'recursive', '0'), self.config_ms)
+        if self.recursive and getattr(flags, 'write_to_files', None):
+            raise NotImplementedError('--write_to_files not implemented for --recursive (same as the reference, :187-188)')
         self.max_batch = int(getattr(flags, 'batch', None) or 8)
         exp_name = os.path.basename(experiment_dir)
         self.out_dir = os.path.join(flags.log_dir.rstrip(os.path.sep) + '_test', exp_name)
@@ -172,8 +172,19 @@ class MultiscaleTester(object):
 
     # ---- bpsp evaluation ------------------------------------------------------------------------------------------------
 
+    @staticmethod
+    def _parse_recursive_flag(flag, config_ms):
+        """'auto' -> 3 for the RGB Shared baseline (num_scales == 1), 0 otherwise; a number is taken as is (reference :123-132)."""
+        flag = str(flag or '0')
+        if flag == 'auto':
+            return 3 if (config_ms.rgb_bicubic_baseline and config_ms.num_scales == 1) else 0
+        r = int(flag)
+        if r and not (config_ms.rgb_bicubic_baseline and config_ms.num_scales == 1):
+            raise ValueError('--recursive only makes sense for the RGB Shared baseline (num_scales == 1)')
+        return r
+
     def _padding_fac(self):
-        return 2 ** self.config_ms.num_scales
+        return 2 ** (self.config_ms.num_scales + self.recursive)
 
     def test_all(self, testsets):
         results = [self.test(testset) for testset in testsets]
@@ -211,17 +222,18 @@ class MultiscaleTester(object):
     def per_image_bpsp(self, out, num_subpixels_before_pad):
         """(B,) bpsp of a forward: per-image sums of the NLL maps + the uniform cost of the coarsest scale
         (multiscale_network.Losses.get :145-165, blueprint.get_loss :64-95, evaluated per batch item)."""
-        losses = self.blueprint.losses
-        nats = losses.loss_dmol_rgb(out.S[0].float(), out.P[0]).sum(dim=(1, 2, 3))
-        for s in range(1, len(out.P)):
-            nats = nats + losses.loss_dmol_n(out.bn[s], out.P[s]).sum(dim=(1, 2, 3))
+        nats = None
+        for loss, target, P in out.iter_targets_and_predictions(self.blueprint.losses.loss_dmol_rgb,
+                                                                self.blueprint.losses.loss_dmol_n):
+            n = loss(target, P).sum(dim=(1, 2, 3))
+            nats = n if nats is None else nats + n     # recursive evaluation sums every scale (reference :330-333)
         _, C, H, W = out.S[-1].shape
         nats = nats + C * H * W * float(np.log(out.L[-1]))
         conv = torch.tensor([np.log(2.) * n for n in num_subpixels_before_pad], dtype=torch.float64, device=nats.device)
         return (nats.double() / conv).cpu().numpy()
 
     def _test(self, testset):
-        test_result = TestResult('bpsp')
+        test_result = TestResult('bpsp recursive' if self.recursive else 'bpsp')
         # every auto-crop of every image, grouped by padded shape so that equal shapes share one forward
         items, groups = [], collections.defaultdict(list)
         for i, img_p in enumerate(testset.ps):
@@ -235,7 +247,7 @@ class MultiscaleTester(object):
             for k in range(0, len(idxs), self.max_batch):
                 chunk = idxs[k:k + self.max_batch]
                 batch = torch.cat([items[j]['padded'] for j in chunk], dim=0).to('cuda', torch.float32)
-                out = self.blueprint.forward(batch)
+                out = self.blueprint.forward(batch, self.recursive)
                 bpsp = self.per_image_bpsp(out, [items[j]['n_sub'] for j in chunk])
                 for j, b in zip(chunk, bpsp):
                     items[j]['bpsp'] = float(b)

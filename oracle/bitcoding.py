@@ -102,3 +102,19 @@ def decode(data, sd, hp=net.L3C_HYPER):
             bn_prev = decoded
         assert r.take(4) == MAGIC
     return bn_prev.round().long(), padding_tuple
+
+
+def losses_bpsp_rgb(out, num_subpixels=None):
+    """RGB baselines: every scale is an RGB DMLL on symbols (targets_style 'S', losses shared: multiscale_network.py:136-139).
+    -> (nonrecursive_bpsps, recursive_bpsps or None) like MultiscaleBlueprint.get_loss :64-95."""
+    costs = [float(dmll.nll(dmll.RGB, out.S[i].float(), out.P[i]).sum()) for i in range(len(out.P))]
+    n = num_subpixels or int(np.prod(out.S[0].shape))
+    conv = np.log(2.) * n
+    costs_bpsp = [c / conv for c in costs]
+
+    def nat_count(i):
+        return int(np.prod(out.S[i].shape)) * np.log(256)
+    final_idx = -1 if out.auto_recursive_from is None else out.auto_recursive_from
+    nonrec = costs_bpsp[:out.auto_recursive_from] + [nat_count(final_idx) / conv]
+    rec = costs_bpsp + [nat_count(-1) / conv] if out.auto_recursive_from is not None else None
+    return nonrec, rec

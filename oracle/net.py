@@ -103,3 +103,50 @@ def forward(img, sd, hp=L3C_HYPER):
 def get_P(scale, bn_q, dec_F_prev, sd, hp=L3C_HYPER):
     f = decoder(bn_q, dec_F_prev, sd, scale, hp)
     return prob_clf(f, sd, scale), f
+
+
+# ---- RGB baselines (BicubicSubsampling encoders; configs/ms/cr_rgb_shared.cf, cr_rgb.cf) ---------------------------------------
+
+RGB_SHARED_HYPER = Hyper(num_scales=1, Cf=64, C=3, L=256, K=10, enc_blocks=0, dec_blocks=8, levels_range=None)
+RGB_HYPER = Hyper(num_scales=3, Cf=64, C=3, L=256, K=10, enc_blocks=0, dec_blocks=8, levels_range=None)
+_RGB_MEAN = torch.tensor([0.4488, 0.4371, 0.4040], dtype=torch.float32).reshape(3, 1, 1).mul(255.)
+
+RgbOut = namedtuple('RgbOut', ['S', 'L', 'bn', 'P', 'auto_recursive_from'])
+
+
+def bicubic_encoder(x):
+    """BicubicDownsamplingEnc.forward (modules/net.py:72-80) with resize_bicubic (dataloaders/images_loader.py:277-288):
+    back to 0..255, round to uint8, PIL BICUBIC resize to (int(W*0.5), int(H*0.5)), symbols = pixel values, bn = value - mean."""
+    from PIL import Image
+    import numpy as np
+    u8 = (x + _RGB_MEAN).clamp(0, 255.).round().to(torch.uint8)
+    outs = []
+    for n in range(u8.shape[0]):
+        img = Image.fromarray(u8[n].permute(1, 2, 0).numpy())
+        w, h = img.size
+        img = img.resize((int(w * 0.5), int(h * 0.5)), Image.BICUBIC)
+        outs.append(torch.from_numpy(np.array(img)).permute(2, 0, 1))
+    down = torch.stack(outs, dim=0)
+    return down.float() - _RGB_MEAN, down.long()
+
+
+def forward_rgb(img, sd, hp, dec_skip, auto_recurse=0):
+    """RGB-baseline forward (multiscale_network.py:226-306 with rgb_bicubic_baseline: identity heads, enc.feed_F False)."""
+    scales = list(range(hp.num_scales)) + [-1] * auto_recurse
+    x = conv(img, sd, 'sub_rgb_mean')
+    S, bn = [img.round().long()], [None]
+    inp = x
+    encs = []
+    for _ in scales:
+        b, s = bicubic_encoder(inp)
+        encs.append(b)
+        S.append(s)
+        bn.append(b)
+        inp = b
+    decs = []
+    for i, s in reversed(list(enumerate(scales))):
+        fuse = None if (not dec_skip or s == -1 or s == max(scales)) else decs[0]
+        net = s if s >= 0 else hp.num_scales - 1
+        decs.insert(0, decoder(encs[i], fuse, sd, net, hp))
+    P = [prob_clf(decs[i], sd, s if s >= 0 else hp.num_scales - 1) for i, s in enumerate(scales)]
+    return RgbOut(S, [256] * len(S), bn, P, hp.num_scales if auto_recurse > 0 else None)

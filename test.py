@@ -7,7 +7,7 @@
 
 Prints the mean bpsp of every (test set, experiment, iteration); results are cached in LOG_DIR_test/<experiment>/cache.pkl.
 `--write_to_files` encodes every image to DIR/<name>.l3c with the HIP coder, decodes it again and asserts equality.
-`--recursive` / `--sample` belong to the RGB baselines / sampling path, which are not on this build's hot path.
+`--recursive auto|N` evaluates the RGB Shared baseline recursively; `--sample` (sampling path) is not on this build's hot path.
 """
 import argparse
 import os

@@ -7,6 +7,7 @@ modules imported through oracle/ref_import.py) on seeded inputs that the tests c
 
   ac_kat.npz     range coder:   torchac_backend_cpu.encode_cdf / decode_cdf (torchac.cpp:263-269, :424-430)
   cdf_kat.npz    CDF tables:    torchac._get_uint16_cdf (torchac.py:174-178), Bitcoding._get_uniform_cdf (bitcoding.py:206-210)
+  net_rgb_32x48.npz  RGB baselines (cr_rgb_shared with auto_recurse=3, cr_rgb): S pyramids (PIL bicubic), P, bpsp
   net_32.npz     config[0]:     MultiscaleBlueprint.forward / get_loss, DiscretizedMixLogisticLoss.cdf_step_non_shared,
                                 MultiscaleNetwork.get_P, Bitcoding.encode -> file bytes, Bitcoding.decode
                                 on one 32x32 image with the synthetic checkpoint (helpers/synthetic.py, seed 0)
@@ -220,6 +221,35 @@ def make_net_fixture(H=32, W=32, seed=0, img_seed=0):
     np.savez_compressed(os.path.join(HERE, 'net_32.npz'), **out)
 
 
+def make_rgb_fixtures():
+    """RGB baselines (config 5 family): cr_rgb_shared with auto_recurse=3 and cr_rgb, forward + get_loss on a 32x48 image."""
+    out = {}
+    img = synthetic.make_image(32, 48, 2, 'natural').unsqueeze(0).long()
+    out['img'] = img.numpy().astype(np.uint8)
+    for name, recurse in [('cr_rgb_shared', 3), ('cr_rgb', 0)]:
+        cfg_mine = config_parser.parse_builtin('ms', name)
+        sd = synthetic.make_state_dict(cfg_mine, 0)
+        with ref_import.reference_modules():
+            from fjcommon import config_parser as rcp
+            from blueprints.multiscale_blueprint import MultiscaleBlueprint
+            cfg, _ = rcp.parse('configs/ms/{}.cf'.format(name))
+            bp = MultiscaleBlueprint(cfg)
+            bp.net.load_state_dict(sd, strict=True)
+            bp.set_eval()
+            with torch.no_grad():
+                o = bp.forward(img.float(), recurse)
+                loss = bp.get_loss(o)
+            for i, S in enumerate(o.S):
+                out['{}/S{}'.format(name, i)] = S.numpy().astype(np.int16)
+            for i, P in enumerate(o.P):   # the finest scale every 4th pixel only (fixture size)
+                out['{}/P{}'.format(name, i)] = (P[:, :, ::4, ::4] if i == 0 else P).numpy().copy()
+            out[name + '/nonrecursive_bpsps'] = np.array([float(b) for b in loss.nonrecursive_bpsps])
+            if loss.recursive_bpsps is not None:
+                out[name + '/recursive_bpsps'] = np.array([float(b) for b in loss.recursive_bpsps])
+            print('  rgb', name, [tuple(S.shape) for S in o.S], [float(b) for b in loss.nonrecursive_bpsps])
+    np.savez_compressed(os.path.join(HERE, 'net_rgb_32x48.npz'), **out)
+
+
 def main():
     with ref_import.reference_modules():
         import torchac_backend_cpu
@@ -232,6 +262,8 @@ def main():
         make_cdf_kat(ref_torchac, ref_bitcoding, coders_helpers, DiscretizedMixLogisticLoss)
     print('network fixture')
     make_net_fixture()
+    print('RGB baseline fixtures')
+    make_rgb_fixtures()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

@@ -100,7 +100,17 @@ def test_schema_strict_checks(synthetic_l3c):
     assert schema.non_shared_get_Kp(10, 3) == 120 and schema.non_shared_get_Kp(10, 5) == 150
 
 
-def test_rgb_baselines_are_refused():
+def test_rgb_baseline_models_construct_and_load():
     from l3c_pytorch_amd.modules.multiscale_network import MultiscaleNetwork
-    with pytest.raises(NotImplementedError):
-        MultiscaleNetwork(config_parser.parse_builtin('ms', 'cr_rgb_shared'))
+    from l3c_pytorch_amd.test.multiscale_tester import MultiscaleTester
+    for name, n_keys in [('cr_rgb_shared', 48), ('cr_rgb', 140)]:
+        cfg = config_parser.parse_builtin('ms', name)
+        net = MultiscaleNetwork(cfg)
+        sd = synthetic.make_state_dict(cfg, 0)
+        assert len(sd) == n_keys
+        net.load_state_dict(sd, strict=True)
+    shared = config_parser.parse_builtin('ms', 'cr_rgb_shared')
+    assert MultiscaleTester._parse_recursive_flag('auto', shared) == 3
+    assert MultiscaleTester._parse_recursive_flag('auto', config_parser.parse_builtin('ms', 'cr')) == 0
+    with pytest.raises(ValueError):
+        MultiscaleTester._parse_recursive_flag('2', config_parser.parse_builtin('ms', 'cr_rgb'))

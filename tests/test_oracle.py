@@ -200,3 +200,43 @@ def test_oracle_coder_vs_live_reference_random():
         ref = bytes(backend.encode_cdf(t, torch.from_numpy(sym)))
         assert ac.encode(tab, sym) == ref
         assert (ac.decode(tab, ref) == backend.decode_cdf(t, ref).numpy()).all()
+
+
+def test_rgb_baseline_oracle_matches_reference_fixture(golden):
+    """RGB baselines (config 5 family): PIL-bicubic pyramids are equal, P / bpsp within fp32 tolerance of the reference."""
+    import l3c_pytorch_amd  # noqa: F401
+    from l3c_pytorch_amd.helpers import config_parser, synthetic
+    torch.set_num_threads(1)
+    g = golden('net_rgb_32x48.npz')
+    img = torch.from_numpy(g['img'].astype(np.int64))
+    for name, hp, skip, recurse in [('cr_rgb_shared', onet.RGB_SHARED_HYPER, False, 3), ('cr_rgb', onet.RGB_HYPER, True, 0)]:
+        sd = synthetic.make_state_dict(config_parser.parse_builtin('ms', name), 0)
+        with torch.no_grad():
+            out = onet.forward_rgb(img.float(), sd, hp, skip, recurse)
+        n_scales = len(out.P)
+        assert n_scales == (4 if recurse else 3)
+        for i in range(n_scales + 1):
+            assert (out.S[i].numpy() == g['{}/S{}'.format(name, i)]).all(), (name, i)
+        for i in range(n_scales):
+            P = out.P[i][:, :, ::4, ::4] if i == 0 else out.P[i]
+            assert np.allclose(P.numpy(), g['{}/P{}'.format(name, i)], atol=1e-4, rtol=1e-5), (name, i)
+        nonrec, rec = obc.losses_bpsp_rgb(out)
+        assert np.allclose(nonrec, g[name + '/nonrecursive_bpsps'], rtol=1e-5)
+        if recurse:
+            assert np.allclose(rec, g[name + '/recursive_bpsps'], rtol=1e-5)
+        else:
+            assert rec is None
+
+
+def test_pil_resample_emulation_is_pillow_exact():
+    """helpers/pil_resample.py (the coefficient tables the HIP resampler consumes) against PIL.Image.resize(BICUBIC)."""
+    import l3c_pytorch_amd  # noqa: F401
+    from PIL import Image
+    from l3c_pytorch_amd.helpers import pil_resample as pr
+    rng = np.random.RandomState(0)
+    for (H, W) in [(32, 32), (64, 96), (37, 51), (2, 2), (5, 9), (100, 3), (250, 188), (3, 3)]:
+        img = rng.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+        oh, ow = pr.half_size(H, W)
+        ref = np.array(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
+        got = pr.resample_u8_numpy(img.transpose(2, 0, 1), oh, ow).transpose(1, 2, 0)
+        assert np.array_equal(ref, got), (H, W)
