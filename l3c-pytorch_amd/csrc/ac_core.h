@@ -229,77 +229,6 @@ struct WordSource {
 };
 
 
-// ---- encoder fast path ------------------------------------------------------------------------------------------------
-// encode_symbol() above is the literal statement (a put per run).  The kernel's inner loop uses this variant: when the
-// bits a symbol emits -- first bit, `pending` complements, n-1 further bits -- fit one 32-bit word (practically always:
-// it takes >= 32 pending underflow bits or a 32-bit common prefix to exceed it) they are composed into ONE value and
-// appended with ONE put; anything longer falls back to the literal path.  Bit-identical by construction; the host sim
-// runs the KATs through it.
-template <class Sink>
-L3C_HD void encode_emit_long(Sink &sink, uint32_t low, int n, uint32_t &pending) {
-    put_with_pending(sink, low >> 31, pending);
-    if (n > 1) sink.put((low << 1) >> (33 - n), n - 1);
-}
-
-template <class Sink>
-L3C_HD void encode_symbol_fast(uint32_t &low, uint32_t &high, uint32_t &pending, uint32_t c_lo, uint32_t c_hi, Sink &sink) {
-    interval_update(low, high, c_lo, c_hi);
-    int n, m;
-    uint32_t nl, nh;
-    renorm_counts(low, high, n, m, nl, nh);
-    const uint32_t total = n ? (uint32_t)n + pending : 0u;
-    if (__builtin_expect(total > 32u, 0)) {
-        encode_emit_long(sink, low, n, pending);
-        pending = (uint32_t)m;
-    } else {
-        const uint32_t first = low >> 31;
-        const uint32_t head = (first << pending) | (first ? 0u : ones((int)pending));   // 1 + pending bits
-        const int nn = n ? n - 1 : 0;
-        const uint32_t rest = (low & 0x7FFFFFFFu) >> ((32 - n) & 31);                      // n - 1 bits (n >= 1)
-        const uint32_t v = n ? ((head << nn) | rest) : 0u;
-        sink.put(v, (int)total);
-        pending = n ? (uint32_t)m : pending + (uint32_t)m;
-    }
-    low = nl;
-    high = nh;
-}
-
-
-// ---- encoder lean path -------------------------------------------------------------------------------------------------
-// Same bits as encode_symbol(), ~50 instructions and two rarely-taken branches per symbol (a lone wavefront retires about one
-// instruction per 2 ns on gfx950, so the instruction count IS the per-stream coding time):
-//   * E1/E2 and E3 shifts merged: with t = low' & ~high', the underflow run is the run of leading ones of t << (n+1), and
-//     low = (low' << (n+m)) & 0x7FFFFFFF, high = (high' << (n+m)) | ones(n+m) | 0x80000000 (the bits forced are already
-//     set whenever m == 0);
-//   * pending complements are a carry: the n emitted bits `top` preceded by... first, p complements, rest  ==  the
-//     (n+p)-bit number  top + (ones(p) << (n-1)).
-// Anything outside the common case (zero-width interval, n > 30, more than 32 bits to emit) re-runs the literal path.
-template <class Sink>
-L3C_HD void encode_symbol_lean(uint32_t &low, uint32_t &high, uint32_t &pending, uint32_t w, Sink &sink) {
-    const uint32_t c_lo = interval_lo(w), c_hi = interval_hi(w);
-    const uint32_t range = high - low;
-    const uint32_t hi1 = low - 1u + (uint32_t)(((uint64_t)range * c_hi + c_hi) >> 16);
-    const uint32_t lo1 = low + (uint32_t)(((uint64_t)range * c_lo + c_lo) >> 16);
-    const uint32_t x = lo1 ^ hi1;
-    const int n = clz32(x);
-    if (__builtin_expect(n > 30 || (uint32_t)n + pending > 32u, 0)) {
-        encode_symbol(low, high, pending, c_lo, c_hi, sink);
-        return;
-    }
-    const uint32_t t = lo1 & ~hi1;
-    const int m = clz32(~(t << (n + 1)));
-    const int k = n + m;                                  // <= 31
-    low = (lo1 << k) & 0x7FFFFFFFu;
-    high = (hi1 << k) | ones(k) | 0x80000000u;
-    const uint32_t top = lo1 >> ((32 - n) & 31);
-    const uint32_t carry = ones((int)pending) << ((n - 1) & 31);
-    const uint32_t v = n ? top + carry : 0u;
-    const uint32_t total = n ? (uint32_t)n + pending : 0u;
-    sink.put(v, (int)total);
-    pending = (n ? 0u : pending) + (uint32_t)m;
-}
-
-
 // ---- two-phase encoder ---------------------------------------------------------------------------------------------------
 // Phase 1 (serial per stream, branch-free): only the interval recurrence.  Per symbol it produces a record
 //     rec_lo = low' (the lower bound right after the interval update, before renormalisation)

@@ -189,13 +189,15 @@ __global__ __launch_bounds__(256, (MT >= 4 ? 2 : 3)) void conv_mfma_kernel(const
     // ---- epilogue: D[i][j]: j = lane&31 (channel), i = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel within the row) ----
     const bool relu = p.epilogue & L3C_EPI_RELU;
     const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
-    const bool interior = oy0 + G::TH <= p.Hout && ox0 + TW <= p.Wout && chunk_o * 64 + 64 <= p.Cout;
+    const bool interior = oy0 + G::TH <= p.Hout && ox0 + TW <= p.Wout;
     if (interior && !shuffle) {
-        // whole tile inside the image: no per-element bounds checks, 32-bit offsets from block-uniform bases
+        // whole tile inside the image: no per-element bounds checks, 32-bit offsets from block-uniform bases; a partial last
+        // output-channel chunk (Kp = 120, 150) only needs a per-lane channel mask
         float *obase = p.out + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + chunk_o * 64;
         const float *rbase = p.res ? p.res + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.res_cstride + p.res_coff + chunk_o * 64 : nullptr;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+            if (chunk_o * 64 + nt * 32 + lx >= p.Cout) continue;
             const float bias = p.bias[chunk_o * 64 + nt * 32 + lx];
             float resv[MT][16];
             if (rbase) {   // all residual loads of this half in flight before the first use
@@ -397,12 +399,13 @@ __global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
         asm volatile("" : "+v"(e_lx), "+v"(e_half), "+v"(e_wave));
         const bool relu = p.epilogue & L3C_EPI_RELU;
         const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
-        const bool interior = oy0 + G::TH <= p.Hout && ox0 + TW <= p.Wout && chunk_o * 64 + 64 <= p.Cout;
+        const bool interior = oy0 + G::TH <= p.Hout && ox0 + TW <= p.Wout;
         if (interior && !shuffle) {
             float *obase = p.out + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.out_cstride + p.out_coff + chunk_o * 64;
             const float *rbase = p.res ? p.res + (((size_t)b * p.Hout + oy0) * p.Wout + ox0) * p.res_cstride + p.res_coff + chunk_o * 64 : nullptr;
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
+                if (chunk_o * 64 + nt * 32 + e_lx >= p.Cout) continue;
                 const float bias = p.bias[chunk_o * 64 + nt * 32 + e_lx];
                 float resv[MT][16];
                 if (rbase) {
@@ -621,8 +624,9 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
     if (d->KS == 3 && d->dilation == 2) return (d->epilogue & 2048) ? launch<3, 1, 2, 16, 2>(p, s) : launch_lds<3, 2>(p, s);
     if (d->KS == 3 && d->dilation == 4) return (d->epilogue & 2048) ? launch<3, 1, 4, 16, 2>(p, s) : launch_lds<3, 4>(p, s);
     if (d->KS == 5) return launch<5, 2, 1, 16, 1>(p, s);
-    // the 1x1 192->Kp layer: v3 (launch_lds<1, 1, 64, 2>) measures the same 70 TFLOP/s as v1 -- it is not operand-bound
-    if ((d->epilogue & 4096) && d->Cin % 64 == 0) return launch_lds<1, 1, 64, 2>(p, s);
+    // the 1x1 192->Kp layer: v3 with both output chunks of Kp = 120 in one block (patch staged once) measures 83 TFLOP/s vs
+    // 78 for v1; with an odd number of chunks (Kp = 150) half a block would idle and v1 wins (64 vs 58)
+    if (!(d->epilogue & 2048) && d->Cin % 64 == 0 && ((d->Cout + 63) / 64) % 2 == 0) return launch_lds<1, 1, 64, 2>(p, s);
     return launch<1, 1, 1, 32, 2>(p, s);
 }
 

@@ -41,10 +41,15 @@ long long hostsim_encode(const uint16_t *cdf, long long row_stride, int Lp, cons
         const uint32_t c_lo = row[x];
         const uint32_t c_hi = x == Lp - 2 ? 0x10000u : row[x + 1];
         const uint32_t w = l3c::pack_interval(c_lo, c_hi);
-        if (fast == 3) { uint32_t rl, rn; l3c::encode_state_step(low, high, w, rl, rn); l3c::emit_record(rl, rn, pending, sink); }
-        else if (fast == 2) l3c::encode_symbol_lean(low, high, pending, w, sink);
-        else if (fast) l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
-        else l3c::encode_symbol(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
+        if (fast) {   // the two-phase encoder's record path (what ac_state_kernel + ac_pack_kernel implement)
+            uint32_t rl, rn;
+            l3c::encode_state_step(low, high, w, rl, rn);
+            const uint32_t r = l3c::pack_record(rl, rn);
+            const uint32_t n = l3c::record_n(r);
+            l3c::emit_record(n ? l3c::record_top(r) << ((32u - n) & 31u) : 0u, n | (l3c::record_m(r) << 8), pending, sink);
+        } else {
+            l3c::encode_symbol(low, high, pending, l3c::interval_lo(w), l3c::interval_hi(w), sink);
+        }
     }
     l3c::encode_finish(low, pending, sink);
     const uint32_t n = sink.finish();

@@ -36,8 +36,8 @@ __global__ __launch_bounds__(64) void enc(const uint32_t *__restrict__ iv, int64
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (MODE >= 2) { lcg = lcg * 1664525u + 1013904223u; uint32_t lo = (lcg >> 8) & 0xFF00u; w[j] = lo | ((lo + 255u) << 16); }
-                    if (LEAN) l3c::encode_symbol_lean(low, high, pending, w[j], sink);
-                    else l3c::encode_symbol_fast(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
+                    if (LEAN) { uint32_t rl, rn; l3c::encode_state_step(low, high, w[j], rl, rn); sink.put(l3c::pack_record(rl, rn) & 1u, 1); }
+                    else l3c::encode_symbol(low, high, pending, l3c::interval_lo(w[j]), l3c::interval_hi(w[j]), sink);
                 }
             }
             if (MODE < 2) { for (int k = 0; k < 4; ++k) cur[k] = nxt[k]; }
@@ -77,10 +77,10 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("%-28s %8.2f ms  %7.1f ns/symbol\n", name, ms, ms * 1e6 / N);
     };
-    time("fast full", [&] { hipLaunchKernelGGL((enc<0, 0>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
-    time("lean full", [&] { hipLaunchKernelGGL((enc<0, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
-    time("lean no stores", [&] { hipLaunchKernelGGL((enc<1, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
-    time("lean no loads no stores", [&] { hipLaunchKernelGGL((enc<3, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("literal encode_symbol", [&] { hipLaunchKernelGGL((enc<0, 0>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("state step only", [&] { hipLaunchKernelGGL((enc<0, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("state step, no stores", [&] { hipLaunchKernelGGL((enc<1, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
+    time("state step, no loads/stores", [&] { hipLaunchKernelGGL((enc<3, 1>), dim3(1), dim3(64), 0, 0, iv, S, N, out, stride, nb); });
     uint32_t *o; hipMalloc(&o, 256);
     const int iters = 1 << 20;
     hipLaunchKernelGGL(chain, dim3(1), dim3(64), 0, 0, o, iters); hipDeviceSynchronize();
