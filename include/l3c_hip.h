@@ -88,6 +88,21 @@ int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t
                   uint32_t *out_nbytes, void *workspace, l3c_stream_t stream);
 
 /*
+ * Grouped form of l3c_ac_encode: ONE phase-1 launch and ONE phase-2 launch cover any number of groups of equally long
+ * streams (the four scales of a batch; or every batch of a heterogeneous image set), so all of them are coded concurrently
+ * without relying on stream-level concurrency.  Descriptors are given in HOST memory; pointers inside are device pointers.
+ *   workspace  l3c_ac_encode_groups_workspace_bytes(n_groups, total number of streams) bytes, 16-byte aligned
+ */
+typedef struct {
+    uint32_t *intervals;       /* in/out, clobbered; l3c_interval_words(n_streams, n_sym) words */
+    uint8_t *out;              /* [n_streams][out_stride_bytes] */
+    uint32_t *out_nbytes;      /* [n_streams] */
+    int64_t n_streams, n_sym, out_stride_bytes;
+} l3c_ac_group;
+int64_t l3c_ac_encode_groups_workspace_bytes(int n_groups, int64_t total_streams);
+int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *workspace, l3c_stream_t stream);
+
+/*
  * Range-decode n_streams streams, one wavefront per stream (the 64 lanes hold the CDF row of the current symbol and
  * rank the decoder's `count` against it).  Bit-exact restatement of decode() (torchac.cpp:299-381) including the
  * reference binary search (binsearch :276-296) and the skipped state update of the last symbol.

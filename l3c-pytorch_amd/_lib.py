@@ -29,6 +29,12 @@ class ConvDesc(ctypes.Structure):
                 ('KS', c_int), ('stride', c_int), ('dilation', c_int), ('epilogue', c_int)]
 
 
+class AcGroup(ctypes.Structure):
+    """l3c_ac_group (include/l3c_hip.h)."""
+    _fields_ = [('intervals', c_vp), ('out', c_vp), ('out_nbytes', c_vp),
+                ('n_streams', c_i64), ('n_sym', c_i64), ('out_stride_bytes', c_i64)]
+
+
 EPI_RELU, EPI_RESIDUAL, EPI_PIXEL_SHUFFLE = 1, 2, 4
 
 # name -> (restype, argtypes); must list every symbol include/l3c_hip.h declares (tests/test_abi.py checks)
@@ -43,6 +49,8 @@ PROTOTYPES = {
     'l3c_ac_max_bytes': (c_i64, [c_i64]),
     'l3c_ac_encode_workspace_bytes': (c_i64, [c_i64]),
     'l3c_ac_encode': (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    'l3c_ac_encode_groups_workspace_bytes': (c_i64, [c_int, c_i64]),
+    'l3c_ac_encode_groups': (c_int, [ctypes.POINTER(AcGroup), c_int, c_vp, c_vp]),
     'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     'l3c_cdf_check_monotone': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     'l3c_dmll_channel_params': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),

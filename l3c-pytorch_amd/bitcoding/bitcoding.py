@@ -10,7 +10,8 @@ What changed is WHERE the work happens.  The reference loops over scales and cha
 channel, and range-codes it on one CPU thread (coders.py:38-66 -> torchac.cpp).  Here a batch of B equally sized images
 is pushed through
     encoder:  net forward  ->  per scale ONE fused kernel P,symbols -> coding intervals of all B*C streams
-              ->  ONE range-coder launch per scale (a stream per lane)            -> bytes + lengths in HBM
+              ->  ONE grouped range-coder launch over all scales (and, with encode_many, over all batches of a
+                  heterogeneous image set)                                         -> bytes + lengths in HBM
     decoder:  per scale get_P -> parameters -> uint16 tables -> ONE range-decoder launch (a stream per wavefront);
               only the RGB scale is serial in its channels (R -> G -> B, the lambda coupling of logistic_mixture.py:262-272)
 and only finished byte strings cross PCIe.  `encode_batch` / `decode_batch` are the native entry points; `encode` /
@@ -62,6 +63,7 @@ class EncodedBatch(object):
         self.B = B
         self.padded_shape = padded_shape     # (H, W) of the padded images
         self.scales = []                     # (C, H, W, out uint8 (B*C, stride), nbytes int32 (B*C,))
+        self.pending = []                    # (C, H, W, intervals) of prepare_batch, consumed by Bitcoding.code
         self.done = []                       # events on the coder streams; wait() orders the current stream after them
 
     def wait(self):
@@ -128,16 +130,22 @@ class Bitcoding(object):
             self.compute_stream = _lib.cu_range_stream(0, n_cu - coder_cus)
             self._coder_range = (n_cu - coder_cus, coder_cus)
 
-    def _streams(self, n):
-        """Side streams for the range coder: its launches are a handful of long-running wavefronts (one lane per
-        stream), so they are overlapped with whatever the main stream does next (the next batch's convolutions)."""
-        if self._coder_streams is None or len(self._coder_streams) < n:
+    N_SIDE_STREAMS = 4
+
+    def _side_stream(self):
+        """Side stream for the range coder: its launches are a handful of long-running wavefronts (a lane per stream),
+        so they are overlapped with whatever the main stream does next (the next batch's convolutions).  Consecutive
+        calls rotate over N_SIDE_STREAMS streams so that the coder launches of successive batches may overlap too."""
+        if self._coder_streams is None:
             if self.coder_cus:
                 from .. import _lib
-                self._coder_streams = [_lib.cu_range_stream(*self._coder_range) for _ in range(n)]
+                make = lambda: _lib.cu_range_stream(*self._coder_range)   # noqa: E731
             else:
-                self._coder_streams = [torch.cuda.Stream() for _ in range(n)]
-        return self._coder_streams
+                make = torch.cuda.Stream
+            self._coder_streams = [make() for _ in range(self.N_SIDE_STREAMS)]
+            self._stream_turn = 0
+        self._stream_turn = (self._stream_turn + 1) % self.N_SIDE_STREAMS
+        return self._coder_streams[self._stream_turn]
 
     # ---- constants --------------------------------------------------------------------------------------------------
 
@@ -161,10 +169,10 @@ class Bitcoding(object):
 
     # ---- native batched API -----------------------------------------------------------------------------------------
 
-    def encode_batch(self, imgs, out=None):
-        """imgs: (B,3,H,W), H and W multiples of 2**num_scales, values 0..255 (any dtype / device).
-        Enqueues the whole encode on the current stream and returns an EncodedBatch (no host sync).
-        `out`: a network output for `imgs` computed earlier (avoids a second forward)."""
+    def prepare_batch(self, imgs, out=None):
+        """First half of `encode_batch`: network forward (unless `out` is given) and, per scale, the fused head that
+        turns P and the symbols into the coding intervals of all B*C streams.  Everything is enqueued on the current
+        stream.  -> EncodedBatch whose `pending` list awaits `code()`."""
         net = self.blueprint.net
         fac = 2 ** net.config_ms.num_scales
         B, _, H, W = imgs.shape
@@ -174,9 +182,7 @@ class Bitcoding(object):
         raw = out.raw
         K = net.config_ms.prob.K
         enc = EncodedBatch(B, (H, W))
-        main = torch.cuda.current_stream()
-        side = self._streams(net.scales + 1)
-        for i, (scale, dmll, uniform) in enumerate(self.iter_scale_dmll()):
+        for scale, dmll, uniform in self.iter_scale_dmll():
             sym = raw.sym[scale]
             _, C, Hs, Ws = sym.shape
             if uniform:
@@ -184,17 +190,47 @@ class Bitcoding(object):
                                               broadcast_row=True)
             else:
                 iv = ops.dmll_encode_intervals(raw.P[scale], sym, self._targets(dmll), C, K, dmll.rgb_scale)
-            ready = torch.cuda.Event()
-            ready.record(main)
-            with torch.cuda.stream(side[i]):
-                side[i].wait_event(ready)
-                iv.record_stream(side[i])
-                stream_bytes, nbytes = ops.ac_encode(iv, B * C, Hs * Ws)
-                done = torch.cuda.Event()
-                done.record(side[i])
-            enc.scales.append((C, Hs, Ws, stream_bytes, nbytes))
-            enc.done.append(done)
+            enc.pending.append((C, Hs, Ws, iv))
         return enc
+
+    def code(self, batches):
+        """Second half: ONE grouped range-coder launch (l3c_ac_encode_groups) over every scale of every prepared batch
+        -- all their streams are coded concurrently, whatever the image sizes -- on a side stream that the current
+        stream does not wait for.  Returns `batches`."""
+        groups, owners = [], []
+        for enc in batches:
+            for C, Hs, Ws, iv in enc.pending:
+                groups.append((iv, enc.B * C, Hs * Ws))
+                owners.append((enc, C, Hs, Ws))
+        if not groups:
+            return batches
+        main, side = torch.cuda.current_stream(), self._side_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            for iv, _, _ in groups:
+                iv.record_stream(side)
+            results, ws = ops.ac_encode_groups(groups)
+            done = torch.cuda.Event()
+            done.record(side)
+        for (enc, C, Hs, Ws), (stream_bytes, nbytes) in zip(owners, results):
+            enc.scales.append((C, Hs, Ws, stream_bytes, nbytes))
+        for enc in batches:
+            enc.pending = []
+            enc.done.append(done)
+        return batches
+
+    def encode_batch(self, imgs, out=None):
+        """imgs: (B,3,H,W), H and W multiples of 2**num_scales, values 0..255 (any dtype / device).
+        Enqueues the whole encode and returns an EncodedBatch (no host sync).
+        `out`: a network output for `imgs` computed earlier (avoids a second forward)."""
+        return self.code([self.prepare_batch(imgs, out)])[0]
+
+    def encode_many(self, batches):
+        """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries -- images of different sizes
+        cannot share a batch).  Forward + heads of all of them, then ONE grouped coder launch.  -> list of EncodedBatch."""
+        return self.code([self.prepare_batch(x) for x in batches])
 
     def decode_batch(self, files):
         """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU,

@@ -11,6 +11,8 @@
 //                                 or, for tables not known to be monotone, with the reference's literal binary search
 //                                 over v_readlane; the coder state lives in SGPRs (wave-uniform)
 //   check_monotone_kernel         flags tables that are not strictly increasing (selects the decode path)
+#include <vector>
+
 #include "ac_core.h"
 #include "l3c_common.h"
 
@@ -44,9 +46,9 @@ __global__ __launch_bounds__(256) void intervals_from_table_kernel(const uint16_
 // Reads 16 interval words at a time (4 x dwordx4, next group prefetched) and overwrites each with its record
 // (csrc/ac_core.h: pack_record) -- same address, so no extra memory and no read/write hazard (a lane only ever touches its
 // own 64-word runs, in order).
-__global__ __launch_bounds__(64) void ac_state_kernel(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
-                                                      uint32_t *__restrict__ final_low) {
-    int64_t s = (int64_t)blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void ac_state_body(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
+                                              uint32_t *__restrict__ final_low, int64_t block) {
+    int64_t s = block * 64 + threadIdx.x;
     const bool active = s < n_streams;
     if (!active) s = n_streams - 1;   // keep the wavefront converged; duplicates rewrite identical values
     uint32_t low = 0, high = 0xFFFFFFFFu;
@@ -101,6 +103,43 @@ __global__ __launch_bounds__(64) void ac_state_kernel(uint32_t *__restrict__ iv,
     if (active) final_low[s] = low;
 }
 
+// One group of equally long streams for the grouped launches (mirrors l3c_ac_group of include/l3c_hip.h).
+struct AcGroup {
+    uint32_t *intervals;
+    uint8_t *out;
+    uint32_t *out_nbytes;
+    uint32_t *final_low;
+    int64_t n_streams, n_sym, out_stride;
+};
+
+struct AcGroupPack {
+    static constexpr int N = 64;
+    AcGroup g[N];
+};
+
+__global__ __launch_bounds__(64) void ac_groups_upload_kernel(AcGroupPack pack, AcGroup *__restrict__ dst, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = pack.g[threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void ac_state_kernel(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
+                                                      uint32_t *__restrict__ final_low) {
+    ac_state_body(iv, n_streams, n_sym, final_low, blockIdx.x);
+}
+
+// Grouped launch: block -> (group, 64-stream block inside the group) by walking the (short) descriptor array.
+__global__ __launch_bounds__(64) void ac_state_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
+    int64_t blk = blockIdx.x;
+    int g = 0;
+    for (; g < n_groups; ++g) {
+        const int64_t nb = (groups[g].n_streams + 63) / 64;
+        if (blk < nb) break;
+        blk -= nb;
+    }
+    if (g >= n_groups) return;
+    const AcGroup gr = groups[g];
+    ac_state_body(gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, blk);
+}
+
 // ---- encoder, phase 2: records -> bits, one stream per wavefront, 64 symbols per step ------------------------------------
 struct GlobalWordStore {
     uint32_t *words;
@@ -115,11 +154,10 @@ __device__ __forceinline__ uint32_t wave_shfl_up(uint32_t v, int d, int lane) {
     return lane >= d ? o : 0u;
 }
 
-__global__ __launch_bounds__(64) void ac_pack_kernel(const uint32_t *__restrict__ rec, int64_t n_streams, int64_t n_sym,
-                                                     const uint32_t *__restrict__ final_low, uint8_t *__restrict__ out,
-                                                     int64_t out_stride, uint32_t *__restrict__ out_nbytes) {
-    __shared__ uint32_t buf[80];   // the bits of one 64-symbol step: <= 31 carried + 64 * 32 new = 2079 bits = 65 words
-    const int64_t s = blockIdx.x;
+__device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__restrict__ rec, int64_t n_streams,
+                                             int64_t n_sym, const uint32_t *__restrict__ final_low,
+                                             uint8_t *__restrict__ out, int64_t out_stride,
+                                             uint32_t *__restrict__ out_nbytes, int64_t s) {
     const int lane = threadIdx.x;
     uint32_t *words = reinterpret_cast<uint32_t *>(out + s * out_stride);
     uint32_t pending = 0;          // wave-uniform
@@ -223,6 +261,26 @@ __global__ __launch_bounds__(64) void ac_pack_kernel(const uint32_t *__restrict_
         const uint32_t nbytes = sink.finish();
         if (lane == 0) out_nbytes[s] = nbytes;
     }
+}
+
+__global__ __launch_bounds__(64) void ac_pack_kernel(const uint32_t *__restrict__ rec, int64_t n_streams, int64_t n_sym,
+                                                     const uint32_t *__restrict__ final_low, uint8_t *__restrict__ out,
+                                                     int64_t out_stride, uint32_t *__restrict__ out_nbytes) {
+    __shared__ uint32_t buf[80];   // the bits of one 64-symbol step: <= 31 carried + 64 * 32 new = 2079 bits = 65 words
+    ac_pack_body(buf, rec, n_streams, n_sym, final_low, out, out_stride, out_nbytes, blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
+    __shared__ uint32_t buf[80];
+    int64_t blk = blockIdx.x;
+    int g = 0;
+    for (; g < n_groups; ++g) {
+        if (blk < groups[g].n_streams) break;
+        blk -= groups[g].n_streams;
+    }
+    if (g >= n_groups) return;
+    const AcGroup gr = groups[g];
+    ac_pack_body(buf, gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, gr.out, gr.out_stride, gr.out_nbytes, blk);
 }
 
 // ---- decoder -------------------------------------------------------------------------------------------------------
@@ -439,6 +497,49 @@ int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t
     hipLaunchKernelGGL(ac_pack_kernel, dim3((unsigned)n_streams), dim3(64), 0, l3c::as_stream(stream), intervals,
                        n_streams, n_sym, final_low, out, out_stride_bytes, out_nbytes);
     return l3c::check_launch("ac_pack_kernel");
+}
+
+int64_t l3c_ac_encode_groups_workspace_bytes(int n_groups, int64_t total_streams) {
+    return (((int64_t)n_groups * (int64_t)sizeof(AcGroup) + 255) / 256) * 256 + ((total_streams * 4 + 255) / 256) * 256;
+}
+
+int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *workspace, l3c_stream_t stream) {
+    L3C_REQUIRE(groups_host && workspace && n_groups > 0 && n_groups <= 65536, "bad arguments");
+    L3C_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "misaligned workspace");
+    std::vector<AcGroup> host((size_t)n_groups);
+    int64_t state_blocks = 0, pack_blocks = 0, streams = 0;
+    const size_t desc_bytes = (((size_t)n_groups * sizeof(AcGroup) + 255) / 256) * 256;
+    uint32_t *final_low = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + desc_bytes);
+    for (int g = 0; g < n_groups; ++g) {
+        const l3c_ac_group &in = groups_host[g];
+        L3C_REQUIRE(in.intervals && in.out && in.out_nbytes, "null pointer in group");
+        L3C_REQUIRE(in.n_streams > 0 && in.n_sym > 0, "empty group");
+        L3C_REQUIRE(in.out_stride_bytes % 4 == 0 && in.out_stride_bytes >= l3c_ac_max_bytes(in.n_sym), "output stride too small");
+        L3C_REQUIRE((reinterpret_cast<uintptr_t>(in.out) & 3) == 0 && (reinterpret_cast<uintptr_t>(in.intervals) & 15) == 0,
+                    "misaligned buffer in group");
+        host[g] = AcGroup{in.intervals, in.out, in.out_nbytes, final_low + streams, in.n_streams, in.n_sym, in.out_stride_bytes};
+        state_blocks += (in.n_streams + 63) / 64;
+        pack_blocks += in.n_streams;
+        streams += in.n_streams;
+    }
+    L3C_REQUIRE(pack_blocks < (1ll << 31), "too many streams");
+    // The descriptors travel as by-value kernel arguments (copied at launch time, so nothing here has to outlive the
+    // call and no host-side synchronisation is needed), 64 per launch.
+    AcGroup *dev = static_cast<AcGroup *>(workspace);
+    int rc;
+    for (int g0 = 0; g0 < n_groups; g0 += AcGroupPack::N) {
+        AcGroupPack pack;
+        const int n = n_groups - g0 < AcGroupPack::N ? n_groups - g0 : AcGroupPack::N;
+        for (int i = 0; i < n; ++i) pack.g[i] = host[(size_t)(g0 + i)];
+        hipLaunchKernelGGL(ac_groups_upload_kernel, dim3(1), dim3(64), 0, l3c::as_stream(stream), pack, dev + g0, n);
+        rc = l3c::check_launch("ac_groups_upload_kernel");
+        if (rc != L3C_OK) return rc;
+    }
+    hipLaunchKernelGGL(ac_state_groups_kernel, dim3((unsigned)state_blocks), dim3(64), 0, l3c::as_stream(stream), dev, n_groups);
+    rc = l3c::check_launch("ac_state_groups_kernel");
+    if (rc != L3C_OK) return rc;
+    hipLaunchKernelGGL(ac_pack_groups_kernel, dim3((unsigned)pack_blocks), dim3(64), 0, l3c::as_stream(stream), dev, n_groups);
+    return l3c::check_launch("ac_pack_groups_kernel");
 }
 
 int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t *in, const int64_t *in_offsets,

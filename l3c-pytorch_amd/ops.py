@@ -234,6 +234,25 @@ def ac_encode(iv, n_streams, n_sym):
     return out, nbytes
 
 
+def ac_encode_groups(groups):
+    """groups: list of (iv, n_streams, n_sym).  ONE state launch + ONE pack launch code every stream of every group
+    concurrently.  -> list of (out uint8 (n_streams, stride), nbytes int32 (n_streams,)); the iv buffers are clobbered."""
+    lib = _lib.load()
+    arr = (_lib.AcGroup * len(groups))()
+    res = []
+    total = 0
+    for g, (iv, n_streams, n_sym) in enumerate(groups):
+        stride = lib.l3c_ac_max_bytes(n_sym)
+        out = torch.empty(n_streams, stride, dtype=torch.uint8, device=iv.device)
+        nbytes = torch.empty(n_streams, dtype=torch.int32, device=iv.device)
+        arr[g] = _lib.AcGroup(ptr(iv), ptr(out), ptr(nbytes), n_streams, n_sym, stride)
+        res.append((out, nbytes))
+        total += n_streams
+    ws = torch.empty(lib.l3c_ac_encode_groups_workspace_bytes(len(groups), total), dtype=torch.uint8, device=groups[0][0].device)
+    call('l3c_ac_encode_groups', arr, len(groups), ptr(ws), stream())
+    return res, ws
+
+
 def pack_streams(payloads, device='cuda'):
     """list of bytes -> (uint8 buffer with every stream 4-byte aligned and zero padded, offsets int64, nbytes int32)."""
     import numpy as np

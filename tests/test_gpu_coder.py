@@ -48,6 +48,29 @@ def test_many_streams_vs_oracle(S, N, Lp):
         assert (dec == syms).all(), monotone
 
 
+@pytest.mark.parametrize('n_groups', [1, 4, 70])
+def test_grouped_launch_vs_oracle(n_groups):
+    """l3c_ac_encode_groups: groups of different stream counts / lengths / alphabets in ONE launch pair; n_groups=70
+    crosses the 64-descriptor upload packs.  Every stream must equal the oracle's bytes."""
+    from l3c_pytorch_amd import ops
+    from tests import gpu_util as gu
+    rng = np.random.RandomState(n_groups)
+    shapes = [(int(rng.choice([1, 3, 64, 65, 130])), int(rng.choice([1, 63, 64, 200, 1025])), int(rng.choice([3, 26, 257])))
+              for _ in range(n_groups)]
+    groups, want = [], []
+    for S, N, Lp in shapes:
+        tabs = gu.random_tables(rng, S, N, Lp, shape=rng.choice([0.05, 0.3, 2.0]))
+        syms = gu.sample_symbols(rng, tabs)
+        t = torch.from_numpy(np.ascontiguousarray(tabs).view(np.int16)).cuda().reshape(S * N, Lp)
+        groups.append((ops.intervals_from_table(t, torch.from_numpy(syms).cuda(), S, N), S, N))
+        want.append([oracle_ac.encode(tabs[s], syms[s]) for s in range(S)])
+    res, _ = ops.ac_encode_groups(groups)
+    for g, ((out, n), w) in enumerate(zip(res, want)):
+        n, out = n.cpu().numpy(), out.cpu().numpy()
+        for s in range(len(w)):
+            assert out[s, :n[s]].tobytes() == w[s], (g, s, shapes[g])
+
+
 def test_uniform_row_broadcast():
     from l3c_pytorch_amd import ops
     from l3c_pytorch_amd.bitcoding.bitcoding import uniform_cdf_row

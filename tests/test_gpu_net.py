@@ -122,6 +122,21 @@ def test_encode_decode_lossless(blueprint, H, W, B, kind):
     assert len(files[0]) - n_payload == 116
 
 
+def test_encode_many_heterogeneous_equals_per_batch(blueprint):
+    """encode_many: batches of different shapes share ONE grouped coder launch; bytes equal encode_batch's."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.helpers import synthetic
+    bc = Bitcoding(blueprint)
+    shapes = [(2, 32, 48), (1, 64, 64), (3, 16, 8), (1, 128, 72)]
+    batches = [torch.stack([synthetic.make_image(H, W, 50 + 7 * k + i, 'natural') for i in range(B)]).long()
+               for k, (B, H, W) in enumerate(shapes)]
+    many = [e.to_bytes() for e in bc.encode_many(batches)]
+    for x, files in zip(batches, many):
+        assert files == bc.encode_batch(x).to_bytes()
+        dec, _ = bc.decode_batch(files)
+        assert torch.equal(dec.cpu(), x)
+
+
 def test_file_api_with_padding_and_reference_file_size(golden, blueprint, tmp_path):
     """reference API: encode(img, path) -> bpsp, decode(path) -> 1CHW long; odd sizes are centre padded."""
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
