@@ -6,10 +6,11 @@
 //                                 a record (top bits, n, m)
 //   ac_pack_kernel                encoder phase 2, one stream per WAVEFRONT, 64 symbols per step: pending runs by a segmented
 //                                 wave scan, bit offsets by a prefix sum, bits merged with LDS atomics, words written coalesced
-//   ac_decode_kernel              one stream per WAVEFRONT: lanes hold the CDF row of the current symbol (prefetched 4
-//                                 symbols ahead); `count` is ranked against the row with v_cmp + s_bcnt1 (ballot/popcount)
-//                                 or, for tables not known to be monotone, with the reference's literal binary search
-//                                 over v_readlane; the coder state lives in SGPRs (wave-uniform)
+//   ac_decode_ring_kernel         one stream per WAVEFRONT: the table streams through an LDS ring by LDS-DMA, lanes hold the CDF
+//                                 row of the current symbol; the symbol is ranked against the row with v_cmp + s_bcnt1
+//                                 (division-free) or, for tables not known to be monotone, with the reference's literal
+//                                 binary search over v_readlane; the coder state lives in SGPRs (wave-uniform)
+//   ac_decode_const_row_kernel    the same for one row shared by all symbols (the uniform prior of the coarsest scale)
 //   check_monotone_kernel         flags tables that are not strictly increasing (selects the decode path)
 #include <vector>
 
@@ -284,151 +285,341 @@ __global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__res
 }
 
 // ---- decoder -------------------------------------------------------------------------------------------------------
+// One stream per WAVEFRONT.  The coder state (low, high, value, bit reader) is wave-uniform and lives in SGPRs; the 64 lanes
+// hold the CDF row of the current symbol (lane l: entries l + 64 j), so the symbol search is one compare + ballot + popcount
+// per 64 entries instead of the reference's binary search (torchac.cpp:286-307), and the two interval bounds are v_readlanes.
+//
+// Row registers are NAMED scalars (Regs<1> / Regs<4>), not arrays: with arrays the compiler turned the wave-uniform select
+// over j into an indexed load from an LDS-promoted alloca -- two LDS round trips on the serial chain of every symbol.
 
-// Wave-uniform word source: a 64-word window of the stream per VGPR (lane l holds word base + l), the next window
-// prefetched; fetch(i) is a v_readlane.
-struct WaveFetch {
+template <int NJ>
+struct Regs;
+template <>
+struct Regs<1> {
+    uint32_t a;
+};
+template <>
+struct Regs<4> {
+    uint32_t a, b, c, d;
+};
+
+__device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t count_le(uint32_t v, uint32_t bound) {
+    return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(v <= bound));
+}
+__device__ __forceinline__ uint32_t scale16(uint32_t range, uint32_t c) {   // (span * c) >> 16, span = range + 1
+    return (uint32_t)(((uint64_t)range * c + c) >> 16);
+}
+
+// entries past the top symbol become 0x10000: never <= a 16-bit count, and scaled they exceed every value - low
+__device__ __forceinline__ void regs_mask(Regs<1> &r, int lane, int top) { r.a = lane <= top ? r.a : 0x10000u; }
+__device__ __forceinline__ void regs_mask(Regs<4> &r, int lane, int top) {
+    r.a = lane <= top ? r.a : 0x10000u;
+    r.b = lane + 64 <= top ? r.b : 0x10000u;
+    r.c = lane + 128 <= top ? r.c : 0x10000u;
+    r.d = lane + 192 <= top ? r.d : 0x10000u;
+}
+__device__ __forceinline__ Regs<1> regs_scale(const Regs<1> &r, uint32_t range) { return Regs<1>{scale16(range, r.a)}; }
+__device__ __forceinline__ Regs<4> regs_scale(const Regs<4> &r, uint32_t range) {
+    return Regs<4>{scale16(range, r.a), scale16(range, r.b), scale16(range, r.c), scale16(range, r.d)};
+}
+__device__ __forceinline__ uint32_t regs_rank(const Regs<1> &r, uint32_t bound) { return count_le(r.a, bound); }
+__device__ __forceinline__ uint32_t regs_rank(const Regs<4> &r, uint32_t bound) {
+    return (count_le(r.a, bound) + count_le(r.b, bound)) + (count_le(r.c, bound) + count_le(r.d, bound));
+}
+__device__ __forceinline__ uint32_t regs_fetch(const Regs<1> &r, uint32_t m) { return lane_read(r.a, m & 63u); }
+__device__ __forceinline__ uint32_t regs_fetch(const Regs<4> &r, uint32_t m) {   // m is wave-uniform
+    const uint32_t l = m & 63u, j = m >> 6;
+    const uint32_t a = lane_read(r.a, l), b = lane_read(r.b, l), c = lane_read(r.c, l), d = lane_read(r.d, l);
+    const uint32_t ab = j & 1u ? b : a, cd = j & 1u ? d : c;
+    return j & 2u ? cd : ab;
+}
+__device__ __forceinline__ Regs<1> regs_load(const uint16_t *row, int lane, int top) {
+    return Regs<1>{lane <= top ? (uint32_t)row[lane] : 0x10000u};
+}
+__device__ __forceinline__ void regs_load_into(Regs<1> &r, const uint16_t *row, int lane, int top) {
+    r.a = lane <= top ? (uint32_t)row[lane] : 0x10000u;
+}
+__device__ __forceinline__ void regs_load_into(Regs<4> &r, const uint16_t *row, int lane, int top) {
+    r.a = lane <= top ? (uint32_t)row[lane] : 0x10000u;
+    r.b = lane + 64 <= top ? (uint32_t)row[lane + 64] : 0x10000u;
+    r.c = lane + 128 <= top ? (uint32_t)row[lane + 128] : 0x10000u;
+    r.d = lane + 192 <= top ? (uint32_t)row[lane + 192] : 0x10000u;
+}
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Wave-uniform bit reader.  The current 64-word window of the stream sits in one VGPR (lane l: word base + l, byte-swapped
+// and tail-masked); the NEXT window is requested by LDS-DMA into a 2 x 256-byte LDS buffer when a window becomes current and
+// picked up from there 64 words later.  No VGPR is the target of a load in the decode loop, so the compiler has nothing to
+// put an s_waitcnt vmcnt on (every such wait would also drain the table DMAs of the ring decoder).  `age` counts table blocks
+// started since the request: after 3 blocks the in-order vmcnt waits of the ring decoder have covered it, otherwise (short
+// streams, the constant-row kernel) the switch waits for everything.  take() is branch-free except for the window switch.
+struct WaveBits {
     const uint32_t *words;   // 4-byte aligned start of the stream
     uint32_t nbytes;
-    uint32_t base;           // first word index of `cur`
-    uint32_t cur, nxt;       // per-lane window registers
     int lane;
-    __device__ __forceinline__ uint32_t load_window(uint32_t b) const {
+    uint32_t lds;            // LDS byte address of the 2 window buffers
+    uint32_t base;           // first word index of `cur`
+    uint32_t cur;            // per-lane window register
+    uint32_t age;
+    uint64_t acc;            // low `nb` bits are unread stream bits
+    int nb;
+    uint32_t next;           // next word index to pull into acc
+
+    __device__ __forceinline__ void request(uint32_t b) {   // window starting at word b -> buffer (b / 64) & 1
         const uint32_t idx = b + (uint32_t)lane;
-        const uint32_t byte0 = idx * 4u;
-        uint32_t w = 0;
+        if (idx * 4u < nbytes)    // lanes past the end leave stale LDS behind; finalise() zeroes them
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(words + idx),
+                                             (__attribute__((address_space(3))) void *)(uintptr_t)(lds + ((b >> 6) & 1u) * 256u),
+                                             4, 0, 0);
+        age = 0;
+    }
+    __device__ __forceinline__ uint32_t pick_up(uint32_t b) const {
+        uint32_t raw;
+        const uint32_t addr = lds + ((b >> 6) & 1u) * 256u + (uint32_t)lane * 4u;
+        asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(addr) : "memory");
+        const uint32_t byte0 = (b + (uint32_t)lane) * 4u;
+        uint32_t w = l3c::bswap32(raw);
         if (byte0 < nbytes) {
-            w = l3c::bswap32(words[idx]);
-            const uint32_t rem = nbytes - byte0;          // valid bytes in this word
+            const uint32_t rem = nbytes - byte0;   // valid bytes in this word
             if (rem < 4u) w &= 0xFFFFFFFFu << (8u * (4u - rem));
+        } else {
+            w = 0u;
         }
         return w;
     }
-    __device__ __forceinline__ void init() {
+    __device__ __forceinline__ void init(const uint32_t *w, uint32_t n, int lane_, uint32_t lds_addr) {
+        words = w;
+        nbytes = n;
+        lane = lane_;
+        lds = lds_addr;
         base = 0;
-        cur = load_window(0);
-        nxt = load_window(64);
+        request(0);
+        request(64);
+        vm_wait<0>();
+        cur = pick_up(0);
+        age = 3;
+        acc = 0;
+        nb = 0;
+        next = 0;
     }
-    __device__ __forceinline__ uint32_t operator()(uint32_t i) {
-        if (i >= base + 64u) {   // wave-uniform
+    __device__ __forceinline__ uint32_t take(int count) {   // next `count` (0..32) bits, MSB first; zeros past the end
+        const uint32_t w = lane_read(cur, next - base);
+        const bool need = nb < count;
+        acc = need ? ((acc << 32) | w) : acc;
+        nb += need ? 32 : 0;
+        next += need ? 1u : 0u;
+        if (next - base >= 64u) {   // window exhausted (wave-uniform, once per 64 words)
             base += 64u;
-            cur = nxt;
-            nxt = load_window(base + 64u);
+            if (age < 3u) vm_wait<0>();
+            cur = pick_up(base);
+            request(base + 64u);
         }
-        return (uint32_t)__builtin_amdgcn_readlane((int)cur, (int)(i - base));
+        nb -= count;
+        return (uint32_t)(acc >> nb) & l3c::ones(count);
     }
 };
 
+// One symbol: search it in `row` (masked by regs_mask), and -- unless it is the stream's last symbol -- advance the state.
+// Fast path (validated table, value inside [low, high] as for every stream this coder or the reference produced):
+// division-free.  cdf[m] <= count  <=>  t[m] = (span * cdf[m]) >> 16 <= value - low, and the scaled entries are exactly the
+// offsets of the interval update (low' = low + t[x], high' = low - 1 + t[x+1]; torchac.cpp:329-345).  low <= high is an
+// invariant of validated tables, so value - low <= high - low is the in-range test.  Masked lanes scale to range + 1 > d.
+// Otherwise: the reference's arithmetic literally (wrapping 64-bit count, its binary search on non-monotone rows).
 template <int NJ>
-struct Row {
-    uint32_t e[NJ];  // lane l holds entries l + 64*j; entries past the top symbol hold 0x10000 (never <= count)
-};
-
-template <int NJ>
-__device__ __forceinline__ Row<NJ> load_row(const uint16_t *tab, int64_t row_stride, int64_t i, int64_t n_sym, int top,
-                                            int lane) {
-    Row<NJ> r;
-    const uint16_t *row = tab + (row_stride ? i * row_stride : 0);
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int idx = lane + 64 * j;
-        r.e[j] = (i < n_sym && idx <= top) ? (uint32_t)row[idx] : 0x10000u;
+__device__ __forceinline__ uint32_t decode_symbol(const Regs<NJ> &row, uint32_t &low, uint32_t &high, uint32_t &value,
+                                                  WaveBits &src, int top, bool monotone, bool advance) {
+    const uint32_t range = high - low, d = value - low;
+    uint32_t x;
+    if (monotone && d <= range && range != 0xFFFFFFFFu) {   // full range (first symbol): a masked entry would scale to 2^32
+        const Regs<NJ> t = regs_scale(row, range);
+        const uint32_t rank = regs_rank(t, d);
+        x = (rank > 1u ? rank : 1u) - 1u;
+        if (advance) {
+            const uint32_t t_lo = regs_fetch(t, x);
+            const uint32_t t_hi = regs_fetch(t, x + 1u);   // x == top: lanes past the top hold range + 1
+            const uint32_t new_low = low + t_lo;
+            const uint32_t new_high = x == (uint32_t)top ? high : low - 1u + t_hi;
+            int n, m;
+            l3c::renorm_counts(new_low, new_high, n, m, low, high);
+            const int c = n + m;
+            if (c <= 32) {   // one read: ((value << n | bits_n) << m ^ msb) | bits_m  ==  (value << c | bits_c) ^ msb
+                const uint32_t bits = src.take(c);
+                value = ((uint32_t)(((uint64_t)value << c)) | bits) ^ (m ? 0x80000000u : 0u);
+            } else {
+                value = n >= 32 ? src.take(32) : ((value << n) | src.take(n));
+                value = ((value << m) ^ 0x80000000u) | src.take(m);
+            }
+        }
+        return x;
     }
-    return r;
+    const uint32_t count = l3c::decode_count(low, high, value);
+    if (monotone) {
+        const uint32_t rank = regs_rank(row, count);
+        x = (rank > 1u ? rank : 1u) - 1u;
+    } else {
+        x = l3c::ref_binsearch([&](uint32_t m) { return regs_fetch(row, m); }, count, (uint32_t)top);
+    }
+    if (advance) {
+        const uint32_t c_lo = regs_fetch(row, x);
+        const uint32_t c_hi = (x == (uint32_t)top) ? 0x10000u : regs_fetch(row, x + 1u);
+        l3c::decode_advance(low, high, value, c_lo, c_hi, src);
+    }
+    return x;
 }
 
-template <int NJ>
-__device__ __forceinline__ uint32_t row_fetch(const Row<NJ> &r, uint32_t m) {
-    uint32_t v = r.e[0];
-#pragma unroll
-    for (int j = 1; j < NJ; ++j) v = ((m >> 6) == (uint32_t)j) ? r.e[j] : v;   // m is wave-uniform
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)(m & 63u));
+// lane (i & 63) keeps symbol i until the 64-symbol block is stored with one coalesced write
+__device__ __forceinline__ void keep_symbol(int16_t *dst, uint32_t i, uint32_t n_sym, uint32_t x, int lane, int &kept) {
+    if ((int)(i & 63u) == lane) kept = (int)x;
+    if ((i & 63u) == 63u || i == n_sym - 1u) {
+        const uint32_t t = (i & ~63u) + (uint32_t)lane;
+        if (t <= i) dst[t] = (int16_t)kept;
+    }
 }
 
+// Every symbol uses the SAME row (row_stride == 0: the uniform prior of the coarsest scale, bitcoding.py:297-323).
 template <int NJ>
-__global__ __launch_bounds__(64) void ac_decode_kernel(const uint16_t *__restrict__ cdf, int64_t row_stride, int Lp,
-                                                       const uint8_t *__restrict__ in,
-                                                       const int64_t *__restrict__ in_offsets,
-                                                       const uint32_t *__restrict__ in_nbytes, int64_t n_sym,
-                                                       int monotone, int16_t *__restrict__ sym_out) {
+__global__ __launch_bounds__(64) void ac_decode_const_row_kernel(const uint16_t *__restrict__ cdf, int Lp,
+                                                                 const uint8_t *__restrict__ in,
+                                                                 const int64_t *__restrict__ in_offsets,
+                                                                 const uint32_t *__restrict__ in_nbytes, uint32_t n_sym,
+                                                                 int monotone, int16_t *__restrict__ sym_out) {
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
     const int top = Lp - 2;
-    const uint16_t *tab = cdf + (row_stride ? s * n_sym * row_stride : 0);
-    int16_t *dst = sym_out + s * n_sym;
+    int16_t *dst = sym_out + s * (int64_t)n_sym;
+    __shared__ __attribute__((aligned(16))) uint8_t window[512];
+    Regs<NJ> row;
+    regs_load_into(row, cdf, lane, top);
+    WaveBits src;
+    src.init(reinterpret_cast<const uint32_t *>(in + in_offsets[s]), in_nbytes[s], lane,
+             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)window);
+    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint32_t value = src.take(32);
+    int kept = 0;
+    for (uint32_t i = 0; i < n_sym; ++i) {
+        const uint32_t x = decode_symbol<NJ>(row, low, high, value, src, top, monotone != 0, i != n_sym - 1u);
+        keep_symbol(dst, i, n_sym, x, lane, kept);
+    }
+}
 
-    WaveFetch wf;
-    wf.words = reinterpret_cast<const uint32_t *>(in + in_offsets[s]);
-    wf.nbytes = in_nbytes[s];
-    wf.lane = lane;
-    wf.init();
-    l3c::WordSource<WaveFetch &> src(wf);
+// Per-symbol rows (row_stride == Lp).  The first version of this kernel kept 4 rows in flight in registers and measured
+// ~630 ns per symbol: the serial chain spent most of its time waiting for HBM.  Here the table streams through an LDS ring
+// with LDS-DMA (`global_load_lds_dwordx4`, no VGPR staging): NB = 4 blocks of R rows; block k+3 is requested when block k
+// starts and block k+1 must have landed by then (s_waitcnt vmcnt(2*IPB): vector-memory operations retire in order), so 2-3
+// blocks (>= 32 symbols, several microseconds) of lookahead are always in flight.  The row of symbol i+1 is read from LDS
+// into registers while symbol i is being decoded.
+//   * The LDS reads are inline asm: the compiler cannot prove that a ds_read does not alias an outstanding LDS-DMA write and
+//     would put vmcnt(0) before every one of them.  They are issued at the top of an iteration and waited for (lgkmcnt(0), an
+//     asm with the registers as in-outs) at its end, so the values are never touched in between.
+//   * DMA windows are 16-byte granules at absolute addresses.  A granule is only requested if it holds at least one byte
+//     of the table (others are redirected to the table's last granule), so the reads never leave the pages of the table.
+template <int NJ>
+struct RingCfg {
+    static constexpr int IPB = NJ == 1 ? 3 : 9;   // 1 KB DMA instructions per block
+    static constexpr int NB = 4;
+    static constexpr int BLOCK_BYTES = IPB * 1024;
+};
+
+__device__ __forceinline__ int ring_rows_per_block(int Lp, int block_bytes) {
+    const int r = (block_bytes - 16) / (Lp * 2);
+    return r < 32 ? r : 32;
+}
+
+__device__ __forceinline__ void lds_row_issue(uint32_t addr, Regs<1> &r) {
+    asm volatile("ds_read_u16 %0, %1" : "=&v"(r.a) : "v"(addr));
+}
+__device__ __forceinline__ void lds_row_issue(uint32_t addr, Regs<4> &r) {
+    asm volatile(
+        "ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384"
+        : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d)
+        : "v"(addr));
+}
+__device__ __forceinline__ void lds_row_wait(Regs<1> &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a)); }
+__device__ __forceinline__ void lds_row_wait(Regs<4> &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d));
+}
+
+template <int NJ>
+__global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__restrict__ cdf, int Lp, int64_t table_bytes,
+                                                            const uint8_t *__restrict__ in,
+                                                            const int64_t *__restrict__ in_offsets,
+                                                            const uint32_t *__restrict__ in_nbytes, uint32_t n_sym,
+                                                            int monotone, int16_t *__restrict__ sym_out) {
+    using C = RingCfg<NJ>;
+    __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int top = Lp - 2;
+    const uint32_t row_bytes = (uint32_t)Lp * 2u;
+    const uint32_t R = (uint32_t)ring_rows_per_block(Lp, C::BLOCK_BYTES);
+    const uint32_t n_blocks = (n_sym + R - 1u) / R;
+    const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
+    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
+    const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
+    int16_t *dst = sym_out + s * (int64_t)n_sym;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
+
+    auto request_block = [&](uint32_t k) {   // DMA the 16-byte granules holding rows [kR, (k+1)R) into slot k % NB
+        const uint64_t a = (stream0 + (uint64_t)k * R * row_bytes) & ~(uint64_t)15;
+        uint8_t *slot = ring + (k % C::NB) * C::BLOCK_BYTES;
+#pragma unroll
+        for (int q = 0; q < C::IPB; ++q) {
+            uint64_t g = a + (uint64_t)(q * 1024 + lane * 16);
+            g = g <= last_granule ? g : last_granule;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(slot + q * 1024), 16, 0, 0);
+        }
+    };
+    auto block_addr = [&](uint32_t k) -> uint32_t {   // LDS byte address of this lane's first entry of row k * R
+        const uint64_t b = stream0 + (uint64_t)k * R * row_bytes;
+        return ring_base + (k % C::NB) * C::BLOCK_BYTES + (uint32_t)(b & 15u) + (uint32_t)lane * 2u;
+    };
+
+    WaveBits src;
+    src.init(reinterpret_cast<const uint32_t *>(in + in_offsets[s]), in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES);
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint32_t value = src.take(32);
 
-    constexpr int D = 4;  // rows in flight
-    Row<NJ> ring[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) ring[d] = load_row<NJ>(tab, row_stride, d, n_sym, top, lane);
+    for (uint32_t k = 0; k < (uint32_t)C::NB - 1u; ++k)
+        if (k < n_blocks) request_block(k);
+    vm_wait<0>();
 
-    int packed_out = 0;  // lane (i & 63) keeps symbol i until the 64-symbol block is stored
-    for (int64_t i0 = 0; i0 < n_sym; i0 += D) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int64_t i = i0 + d;
-            if (i < n_sym) {   // wave-uniform
-                const Row<NJ> row = ring[d];
-                ring[d] = load_row<NJ>(tab, row_stride, i + D, n_sym, top, lane);
-                uint32_t x;
-                const bool in_range = value >= low && value <= high;   // always true for a stream this coder produced
-                if (monotone && in_range) {
-                    // Division-free: cdf[m] <= count  <=>  t[m] = (span * cdf[m]) >> 16 <= value - low, and the scaled entries
-                    // are exactly the interval offsets of the state update (low' = low + t[x], high' = low - 1 + t[x+1]).
-                    const uint32_t range = high - low, d = value - low;
-                    Row<NJ> t;
-                    uint32_t rank = 0;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        t.e[j] = (uint32_t)(((uint64_t)range * row.e[j] + row.e[j]) >> 16);
-                        rank += (uint32_t)__popcll(__ballot(lane + 64 * j <= top && t.e[j] <= d));
-                    }
-                    x = rank ? rank - 1u : 0u;
-                    if ((int)(i & 63) == lane) packed_out = (int)x;
-                    if ((i & 63) == 63 || i == n_sym - 1) {
-                        const int64_t tt = (i & ~(int64_t)63) + lane;
-                        if (tt <= i) dst[tt] = (int16_t)packed_out;
-                    }
-                    if (i != n_sym - 1) {
-                        const uint32_t new_low = low + row_fetch<NJ>(t, x);
-                        const uint32_t new_high = (x == (uint32_t)top) ? high : low - 1u + row_fetch<NJ>(t, x + 1u);
-                        int n, m;
-                        l3c::renorm_counts(new_low, new_high, n, m, low, high);
-                        if (n >= 32) value = src.take(32);
-                        else if (n) value = (value << n) | src.take(n);
-                        if (m) value = ((value << m) ^ 0x80000000u) | src.take(m);
-                    }
-                    continue;
-                }
-                const uint32_t count = l3c::decode_count(low, high, value);
-                if (monotone) {
-                    uint32_t rank = 0;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) rank += (uint32_t)__popcll(__ballot(row.e[j] <= count));
-                    x = rank ? rank - 1u : 0u;
-                } else {
-                    x = l3c::ref_binsearch([&](uint32_t m) { return row_fetch<NJ>(row, m); }, count, (uint32_t)top);
-                }
-                if ((int)(i & 63) == lane) packed_out = (int)x;
-                if ((i & 63) == 63 || i == n_sym - 1) {
-                    const int64_t t = (i & ~(int64_t)63) + lane;
-                    if (t <= i) dst[t] = (int16_t)packed_out;
-                }
-                if (i != n_sym - 1) {
-                    const uint32_t c_lo = row_fetch<NJ>(row, x);
-                    const uint32_t c_hi = (x == (uint32_t)top) ? 0x10000u : row_fetch<NJ>(row, x + 1u);
-                    l3c::decode_advance(low, high, value, c_lo, c_hi, src);
-                }
-            }
+    Regs<NJ> next;
+    lds_row_issue(block_addr(0), next);
+    lds_row_wait(next);
+
+    int kept = 0;
+    uint32_t i = 0;
+    for (uint32_t k = 0; k < n_blocks; ++k) {
+        // Request block k + NB - 1 (its slot held block k - 1, fully consumed), then make sure block k + 1 -- whose first row
+        // is prefetched at the end of this block -- has landed: only the two newest requests may stay in flight.
+        if (k + C::NB - 1u < n_blocks) {
+            request_block(k + C::NB - 1u);
+            if (k > 0) vm_wait<2 * C::IPB>();   // k == 0: blocks 0 .. NB-2 were waited for above
+        } else {
+            vm_wait<0>();
+        }
+        src.age += 1u;
+        const uint32_t i_end = (k + 1u) * R < n_sym ? (k + 1u) * R : n_sym;
+        const uint32_t i_cross = (k + 1u) * R - 1u;   // the symbol whose successor row lives in block k + 1
+        const uint32_t addr_cross = block_addr(k + 1u);
+        uint32_t addr_next = block_addr(k) + row_bytes;
+        for (; i < i_end; ++i) {
+            Regs<NJ> row = next;
+            regs_mask(row, lane, top);
+            lds_row_issue(i == i_cross ? addr_cross : addr_next, next);   // row i + 1 (past the end: never used)
+            addr_next += row_bytes;
+            const uint32_t x = decode_symbol<NJ>(row, low, high, value, src, top, monotone != 0, i != n_sym - 1u);
+            keep_symbol(dst, i, n_sym, x, lane, kept);
+            lds_row_wait(next);
         }
     }
 }
@@ -550,14 +741,24 @@ int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t
     L3C_REQUIRE(row_stride == 0 || row_stride == Lp, "row_stride must be 0 or Lp");
     L3C_REQUIRE(n_streams > 0 && n_sym > 0, "empty input");
     L3C_REQUIRE((reinterpret_cast<uintptr_t>(in) & 3) == 0, "input must be 4-byte aligned (and every offset a multiple of 4)");
+    L3C_REQUIRE(n_sym < (1ll << 31), "n_sym out of range");
+    L3C_REQUIRE((reinterpret_cast<uintptr_t>(cdf) & 1) == 0, "table must be 2-byte aligned");
     const dim3 grid((unsigned)n_streams), block(64);
+    const hipStream_t st = l3c::as_stream(stream);
+    const uint32_t n = (uint32_t)n_sym;
+    if (row_stride == 0) {
+        if (Lp - 1 <= 64)
+            hipLaunchKernelGGL(ac_decode_const_row_kernel<1>, grid, block, 0, st, cdf, Lp, in, in_offsets, in_nbytes, n, monotone, sym_out);
+        else
+            hipLaunchKernelGGL(ac_decode_const_row_kernel<4>, grid, block, 0, st, cdf, Lp, in, in_offsets, in_nbytes, n, monotone, sym_out);
+        return l3c::check_launch("ac_decode_const_row_kernel");
+    }
+    const int64_t table_bytes = n_streams * n_sym * (int64_t)Lp * 2;
     if (Lp - 1 <= 64)
-        hipLaunchKernelGGL(ac_decode_kernel<1>, grid, block, 0, l3c::as_stream(stream), cdf, row_stride, Lp, in,
-                           in_offsets, in_nbytes, n_sym, monotone, sym_out);
+        hipLaunchKernelGGL(ac_decode_ring_kernel<1>, grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, sym_out);
     else
-        hipLaunchKernelGGL(ac_decode_kernel<4>, grid, block, 0, l3c::as_stream(stream), cdf, row_stride, Lp, in,
-                           in_offsets, in_nbytes, n_sym, monotone, sym_out);
-    return l3c::check_launch("ac_decode_kernel");
+        hipLaunchKernelGGL(ac_decode_ring_kernel<4>, grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, sym_out);
+    return l3c::check_launch("ac_decode_ring_kernel");
 }
 
 int l3c_cdf_check_monotone(const uint16_t *cdf, int64_t n_rows, int Lp, int32_t *flag_out, l3c_stream_t stream) {
