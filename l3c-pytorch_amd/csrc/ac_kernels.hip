@@ -329,6 +329,36 @@ __device__ __forceinline__ uint32_t regs_rank(const Regs<1> &r, uint32_t bound) 
 __device__ __forceinline__ uint32_t regs_rank(const Regs<4> &r, uint32_t bound) {
     return (count_le(r.a, bound) + count_le(r.b, bound)) + (count_le(r.c, bound) + count_le(r.d, bound));
 }
+// Lanes holding real table entries (index <= top), as wave-uniform 64-bit masks: the FAST decoder ranks UNMASKED rows and
+// ands the ballots with these (a masked entry 0x10000 would scale to 2^32 = 0 when the interval is the full 32-bit range,
+// which recurs whenever a symbol's interval is an aligned power of two, e.g. a width-1 cdf step coded from the full range).
+template <int NJ>
+struct ValidLanes;
+template <>
+struct ValidLanes<1> {
+    uint64_t a;
+};
+template <>
+struct ValidLanes<4> {
+    uint64_t a, b, c, d;
+};
+__device__ __forceinline__ ValidLanes<1> valid_lanes1(int lane, int top) {
+    return ValidLanes<1>{__builtin_amdgcn_ballot_w64(lane <= top)};
+}
+__device__ __forceinline__ ValidLanes<4> valid_lanes4(int lane, int top) {
+    return ValidLanes<4>{__builtin_amdgcn_ballot_w64(lane <= top), __builtin_amdgcn_ballot_w64(lane + 64 <= top),
+                         __builtin_amdgcn_ballot_w64(lane + 128 <= top), __builtin_amdgcn_ballot_w64(lane + 192 <= top)};
+}
+__device__ __forceinline__ uint32_t count_le_valid(uint32_t v, uint32_t bound, uint64_t valid) {
+    return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(v <= bound) & valid);
+}
+__device__ __forceinline__ uint32_t regs_rank_valid(const Regs<1> &r, uint32_t bound, const ValidLanes<1> &v) {
+    return count_le_valid(r.a, bound, v.a);
+}
+__device__ __forceinline__ uint32_t regs_rank_valid(const Regs<4> &r, uint32_t bound, const ValidLanes<4> &v) {
+    return (count_le_valid(r.a, bound, v.a) + count_le_valid(r.b, bound, v.b)) +
+           (count_le_valid(r.c, bound, v.c) + count_le_valid(r.d, bound, v.d));
+}
 __device__ __forceinline__ uint32_t regs_fetch(const Regs<1> &r, uint32_t m) { return lane_read(r.a, m & 63u); }
 __device__ __forceinline__ uint32_t regs_fetch(const Regs<4> &r, uint32_t m) {   // m is wave-uniform
     const uint32_t l = m & 63u, j = m >> 6;
@@ -415,7 +445,7 @@ struct WaveBits {
         acc = need ? ((acc << 32) | w) : acc;
         nb += need ? 32 : 0;
         next += need ? 1u : 0u;
-        if (next - base >= 64u) {   // window exhausted (wave-uniform, once per 64 words)
+        if (__builtin_expect(next - base >= 64u, 0)) {   // window exhausted (wave-uniform, once per 64 words)
             base += 64u;
             if (age < 3u) vm_wait<0>();
             cur = pick_up(base);
@@ -474,6 +504,47 @@ __device__ __forceinline__ uint32_t decode_symbol(const Regs<NJ> &row, uint32_t 
     return x;
 }
 
+// The fast path alone, for the FAST instantiation of the ring decoder (nothing but this in its loop).  Precondition:
+// validated (strictly increasing) table; `row` is NOT masked, `valid` marks the lanes that hold table entries.  A
+// renormalised interval of a validated table never collapses to one value (its width is >= 2^14), so the n == 32 case of
+// renorm_counts cannot occur.  Returns false -- state untouched -- when value is outside [low, high], which a stream of this
+// coder / the reference never produces; the stream is then decoded again by the generic instantiation.
+template <int NJ>
+__device__ __forceinline__ bool decode_symbol_fast(const Regs<NJ> &row, const ValidLanes<NJ> &valid, uint32_t &low,
+                                                   uint32_t &high, uint32_t &value, WaveBits &src, int top, bool advance,
+                                                   uint32_t &x) {
+    const uint32_t range = high - low, d = value - low;
+    if (__builtin_expect(d > range, 0)) return false;
+    const Regs<NJ> t = regs_scale(row, range);
+    const uint32_t rank = regs_rank_valid(t, d, valid);
+    uint32_t x1 = rank > 1u ? rank : 1u;   // x + 1
+    asm("" : "+s"(x1));                    // keep it scalar: max - 1 would be canonicalised to a VALU-only saturating subtract
+    x = x1 - 1u;
+    if (advance) {
+        const uint32_t t_lo = regs_fetch(t, x);
+        const uint32_t t_hi = regs_fetch(t, x1);   // x == top: not a table entry, replaced below
+        uint32_t lo = low + t_lo;
+        uint32_t hi = x == (uint32_t)top ? high : low - 1u + t_hi;
+        // renorm_counts without its n == 32 case (lo != hi here) and without branches: after the common prefix is shifted out
+        // lo starts with 0 and hi with 1, so the underflow step is the identity for m == 0.
+        const int n = l3c::clz32(lo ^ hi);
+        lo <<= n;
+        hi = ~(~hi << n);
+        const int m = l3c::clz32(~((lo & ~hi) << 1));
+        low = (lo << m) & 0x7FFFFFFFu;
+        high = ~(~hi << m) | 0x80000000u;
+        const int c = n + m;
+        if (__builtin_expect(c <= 32, 1)) {
+            const uint32_t bits = src.take(c);
+            value = ((uint32_t)(((uint64_t)value << c)) | bits) ^ (m ? 0x80000000u : 0u);
+        } else {   // n <= 18 here, m <= 31
+            value = (value << n) | src.take(n);
+            value = ((value << m) ^ 0x80000000u) | src.take(m);
+        }
+    }
+    return true;
+}
+
 // lane (i & 63) keeps symbol i until the 64-symbol block is stored with one coalesced write
 __device__ __forceinline__ void keep_symbol(int16_t *dst, uint32_t i, uint32_t n_sym, uint32_t x, int lane, int &kept) {
     if ((int)(i & 63u) == lane) kept = (int)x;
@@ -516,8 +587,8 @@ __global__ __launch_bounds__(64) void ac_decode_const_row_kernel(const uint16_t 
 // blocks (>= 32 symbols, several microseconds) of lookahead are always in flight.  The row of symbol i+1 is read from LDS
 // into registers while symbol i is being decoded.
 //   * The LDS reads are inline asm: the compiler cannot prove that a ds_read does not alias an outstanding LDS-DMA write and
-//     would put vmcnt(0) before every one of them.  They are issued at the top of an iteration and waited for (lgkmcnt(0), an
-//     asm with the registers as in-outs) at its end, so the values are never touched in between.
+//     would put vmcnt(0) before every one of them.  They are issued at the top of an iteration (lds_row_issue) and waited
+//     for at its end (lds_row_take).
 //   * DMA windows are 16-byte granules at absolute addresses.  A granule is only requested if it holds at least one byte
 //     of the table (others are redirected to the table's last granule), so the reads never leave the pages of the table.
 template <int NJ>
@@ -541,17 +612,27 @@ __device__ __forceinline__ void lds_row_issue(uint32_t addr, Regs<4> &r) {
         : "=&v"(r.a), "=&v"(r.b), "=&v"(r.c), "=&v"(r.d)
         : "v"(addr));
 }
-__device__ __forceinline__ void lds_row_wait(Regs<1> &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a)); }
-__device__ __forceinline__ void lds_row_wait(Regs<4> &r) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d));
+// Wait for the reads of lds_row_issue and move the row out of the registers they target, in ONE asm statement: between the
+// two statements `pending` has no uses, so the compiler has no reason to copy registers whose LDS data is still in flight
+// (it cannot know about that), and what leaves this statement are ordinary, complete values.
+__device__ __forceinline__ void lds_row_take(Regs<1> &row, const Regs<1> &pending) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, %1" : "=&v"(row.a) : "v"(pending.a));
+}
+__device__ __forceinline__ void lds_row_take(Regs<4> &row, const Regs<4> &pending) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                 : "=&v"(row.a), "=&v"(row.b), "=&v"(row.c), "=&v"(row.d)
+                 : "v"(pending.a), "v"(pending.b), "v"(pending.c), "v"(pending.d));
 }
 
-template <int NJ>
+// FAST = true: the loop holds only decode_symbol_fast; a stream that leaves the fast path is marked by the sentinel -1 in its
+// first output symbol and abandoned.  FAST = false: the generic decoder, run afterwards for marked streams only (`force` = 0)
+// or for every stream (`force` = 1: table not validated).
+template <int NJ, bool FAST>
 __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__restrict__ cdf, int Lp, int64_t table_bytes,
                                                             const uint8_t *__restrict__ in,
                                                             const int64_t *__restrict__ in_offsets,
                                                             const uint32_t *__restrict__ in_nbytes, uint32_t n_sym,
-                                                            int monotone, int16_t *__restrict__ sym_out) {
+                                                            int monotone, int force, int16_t *__restrict__ sym_out) {
     using C = RingCfg<NJ>;
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
     const int64_t s = blockIdx.x;
@@ -564,6 +645,7 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
     const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
     int16_t *dst = sym_out + s * (int64_t)n_sym;
+    if (!FAST && !force && dst[0] != (int16_t)-1) return;   // decoded by the FAST pass
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
 
     auto request_block = [&](uint32_t k) {   // DMA the 16-byte granules holding rows [kR, (k+1)R) into slot k % NB
@@ -592,12 +674,15 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
         if (k < n_blocks) request_block(k);
     vm_wait<0>();
 
-    Regs<NJ> next;
-    lds_row_issue(block_addr(0), next);
-    lds_row_wait(next);
+    Regs<NJ> row, pending;
+    lds_row_issue(block_addr(0), pending);
+    lds_row_take(row, pending);
 
     int kept = 0;
     uint32_t i = 0;
+    ValidLanes<NJ> valid;
+    if constexpr (NJ == 1) valid = valid_lanes1(lane, top);
+    else valid = valid_lanes4(lane, top);
     for (uint32_t k = 0; k < n_blocks; ++k) {
         // Request block k + NB - 1 (its slot held block k - 1, fully consumed), then make sure block k + 1 -- whose first row
         // is prefetched at the end of this block -- has landed: only the two newest requests may stay in flight.
@@ -611,15 +696,24 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
         const uint32_t i_end = (k + 1u) * R < n_sym ? (k + 1u) * R : n_sym;
         const uint32_t i_cross = (k + 1u) * R - 1u;   // the symbol whose successor row lives in block k + 1
         const uint32_t addr_cross = block_addr(k + 1u);
-        uint32_t addr_next = block_addr(k) + row_bytes;
+        uint32_t addr_next = block_addr(k) + (i - k * R + 1u) * row_bytes;
         for (; i < i_end; ++i) {
-            Regs<NJ> row = next;
-            regs_mask(row, lane, top);
-            lds_row_issue(i == i_cross ? addr_cross : addr_next, next);   // row i + 1 (past the end: never used)
+            if (!FAST) regs_mask(row, lane, top);
+            lds_row_issue(i == i_cross ? addr_cross : addr_next, pending);   // row i + 1 (past the end: never used)
             addr_next += row_bytes;
-            const uint32_t x = decode_symbol<NJ>(row, low, high, value, src, top, monotone != 0, i != n_sym - 1u);
+            uint32_t x = 0;
+            bool ok = true;
+            if (FAST)
+                ok = decode_symbol_fast<NJ>(row, valid, low, high, value, src, top, i != n_sym - 1u, x);
+            else
+                x = decode_symbol<NJ>(row, low, high, value, src, top, monotone != 0, i != n_sym - 1u);
             keep_symbol(dst, i, n_sym, x, lane, kept);
-            lds_row_wait(next);
+            lds_row_take(row, pending);   // the only take of the loop, on every path (tools/check_asm_prefetch.py)
+            if (FAST && __builtin_expect(!ok, 0)) {
+                vm_wait<0>();
+                if (lane == 0) dst[0] = (int16_t)-1;   // same lane, after any block store: the last write to dst[0]
+                return;
+            }
         }
     }
 }
@@ -754,11 +848,21 @@ int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t
         return l3c::check_launch("ac_decode_const_row_kernel");
     }
     const int64_t table_bytes = n_streams * n_sym * (int64_t)Lp * 2;
-    if (Lp - 1 <= 64)
-        hipLaunchKernelGGL(ac_decode_ring_kernel<1>, grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, sym_out);
+    const bool small = Lp - 1 <= 64;
+    if (monotone) {   // fast pass; streams that leave the fast path mark themselves for the generic pass
+        if (small)
+            hipLaunchKernelGGL((ac_decode_ring_kernel<1, true>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, 1, 0, sym_out);
+        else
+            hipLaunchKernelGGL((ac_decode_ring_kernel<4, true>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, 1, 0, sym_out);
+        const int rc = l3c::check_launch("ac_decode_ring_kernel<fast>");
+        if (rc != L3C_OK) return rc;
+    }
+    const int force = monotone ? 0 : 1;
+    if (small)
+        hipLaunchKernelGGL((ac_decode_ring_kernel<1, false>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, force, sym_out);
     else
-        hipLaunchKernelGGL(ac_decode_ring_kernel<4>, grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, sym_out);
-    return l3c::check_launch("ac_decode_ring_kernel");
+        hipLaunchKernelGGL((ac_decode_ring_kernel<4, false>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, force, sym_out);
+    return l3c::check_launch("ac_decode_ring_kernel<generic>");
 }
 
 int l3c_cdf_check_monotone(const uint16_t *cdf, int64_t n_rows, int Lp, int32_t *flag_out, l3c_stream_t stream) {

@@ -52,3 +52,13 @@ def test_no_cpu_fallback():
     if not torch.cuda.is_available():
         with pytest.raises(_lib.L3CError):
             _lib.require_gpu()
+
+
+def test_ring_decoder_prefetch_registers_untouched():
+    """The ring decoder's LDS row prefetch is inline asm the compiler cannot see into; tools/check_asm_prefetch.py rebuilds
+    the CFG of the compiled kernels and proves no compiler-generated instruction names a register with a read in flight."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_asm_prefetch.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -71,6 +71,52 @@ def test_grouped_launch_vs_oracle(n_groups):
             assert out[s, :n[s]].tobytes() == w[s], (g, s, shapes[g])
 
 
+@pytest.mark.parametrize('Lp', [26, 257])
+def test_full_range_recurs_on_width_one_steps(Lp):
+    """cdf steps of exactly 1 (or an aligned power of two) coded from the full 32-bit range renormalise back to the full
+    range: low = 0, high = 2^32 - 1 recurs symbol after symbol, the case in which a masked 0x10000 entry scales to 2^32."""
+    from tests import gpu_util as gu
+    rng = np.random.RandomState(Lp)
+    S, N = 4, 300
+    tab = np.empty((S, N, Lp), dtype=np.uint16)
+    tab[0] = np.arange(Lp)                                           # width-1 steps, all mass on the top symbol
+    tab[1] = np.minimum(np.arange(Lp) * 2, 65535)                    # width 2
+    tab[2] = np.concatenate([[0], 40000 + np.arange(Lp - 1)])        # a wide symbol 0, then width-1 steps
+    tab[3] = (np.arange(Lp) * (65536 // Lp)).astype(np.uint16)       # near-uniform, for contrast
+    syms = rng.randint(0, Lp - 2, size=(S, N)).astype(np.int16)      # never the heavy top symbol
+    syms[2, ::3] = 0
+    got = gu.hip_encode_streams(tab, syms)
+    for s in range(S):
+        assert got[s] == oracle_ac.encode(tab[s], syms[s]), s
+    for monotone in (True, False):
+        dec = gu.hip_decode_streams(tab, got, monotone)
+        assert (dec == syms).all(), (monotone, [int((dec[s] != syms[s]).sum()) for s in range(S)])
+
+
+@pytest.mark.parametrize('Lp,N', [(257, 700), (26, 3000)])
+def test_foreign_streams_decode_like_the_reference(Lp, N):
+    """Byte strings no encoder produced (random bytes, a stream coded with OTHER tables, an empty one): `value` leaves
+    [low, high], the fast pass marks the stream and the generic pass must reproduce the reference's wrapping arithmetic
+    (torchac.cpp:329) symbol for symbol -- alongside valid streams in the same launch, across several ring blocks."""
+    from tests import gpu_util as gu
+    rng = np.random.RandomState(Lp)
+    S = 6
+    tabs = gu.random_tables(rng, S, N, Lp, shape=0.3)
+    syms = gu.sample_symbols(rng, tabs)
+    other = gu.random_tables(rng, S, N, Lp, shape=2.0)
+    payloads = [oracle_ac.encode(tabs[s], syms[s]) for s in range(S)]
+    payloads[1] = rng.randint(0, 256, size=len(payloads[1]), dtype=np.uint8).tobytes()
+    payloads[2] = oracle_ac.encode(other[2], gu.sample_symbols(rng, other)[2])
+    payloads[3] = b''
+    payloads[4] = payloads[4][:len(payloads[4]) // 3]
+    want = np.stack([oracle_ac.decode(tabs[s], payloads[s], N) for s in range(S)])
+    assert (want[0] == syms[0]).all() and (want[5] == syms[5]).all()
+    for monotone in (True, False):
+        dec = gu.hip_decode_streams(tabs, payloads, monotone)
+        for s in range(S):
+            assert (dec[s] == want[s]).all(), (monotone, s, int((dec[s] != want[s]).sum()))
+
+
 def test_uniform_row_broadcast():
     from l3c_pytorch_amd import ops
     from l3c_pytorch_amd.bitcoding.bitcoding import uniform_cdf_row
