@@ -41,6 +41,7 @@ def parse_args():
     ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
     ap.add_argument('--coder-cus', type=int, default=0, help='compute units reserved for the range coder (0 = share all CUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-decode', action='store_true', help='skip the (untimed-region) decode leg')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events of the roofline leg')
     return ap.parse_args()
 
@@ -71,6 +72,26 @@ def cpu_baseline(sd, synthetic):
             'sample': '1 image 768x512 (natural-like synthetic), oracle.bitcoding.encode: torch-CPU forward + torch CDF '
                       'tables + C range coder, {:.1f} s, {} bytes'.format(dt, len(data)),
             'seconds': round(dt, 2)}
+
+
+def decode_leg(bc, enc, imgs, compute_stream):
+    """Secondary figure (SURVEY.md section 8d "also decode MPix/s"), outside the timed region: decode the last coded batch
+    back from its `.l3c` byte strings (host) to pixels in HBM and check it is lossless.  The range decoder is a serial
+    chain per stream (one wavefront each), so the time hardly depends on the batch size."""
+    SYMBOLS_PER_PX = 4.640625           # 3 P0 + 5 (P1 + P2 + P3) symbols per image pixel, SURVEY.md section 8d
+    with torch.cuda.stream(compute_stream):
+        files = enc.to_bytes()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec, _ = bc.decode_batch(files)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        lossless = bool(torch.equal(dec.to(torch.uint8), imgs.to(torch.uint8)))
+    B = len(files)
+    return {'value': round(B * H * W / 1e6 / dt, 3), 'unit': 'MPix/s', 'batch': B, 'seconds': round(dt, 3),
+            'lossless': lossless, 'msym_per_s_aggregate': round(B * H * W * SYMBOLS_PER_PX / 1e6 / dt, 1),
+            'longest_chain_symbols': 3 * H * W,
+            'note': 'host .l3c bytes -> pixels in HBM; latency-bound: 3 x {} serial symbols per image (R -> G -> B)'.format(H * W)}
 
 
 def main():
@@ -159,6 +180,9 @@ def main():
                         'algorithmic_gflop_per_launch': round(flops / n / 1e9, 3),
                         'all_mfma_convs': {'achieved': round(all_f / all_s / 1e12, 2), 'seconds_per_step': round(all_s / args.steps, 5),
                                            'share_of_step': round(all_s / elapsed, 3)}}
+        decode = None
+        if world == 1 and not args.no_decode:
+            decode = decode_leg(bc, enc, imgs, compute_stream)
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sd, synthetic)
@@ -173,7 +197,7 @@ def main():
             'bpsp': round(bpsp, 4), 'flop_per_px': ALGO_FLOP_PER_PX,
             'end_to_end_tflops': round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / world, 2),
             'device': '{} ({}, {} CUs)'.format(name, arch, ncu),
-            'roofline': roofline, 'cpu_baseline': cpu,
+            'roofline': roofline, 'cpu_baseline': cpu, 'decode': decode,
         }
         print(json.dumps(result))
     if world > 1:
