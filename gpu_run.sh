@@ -1,1 +1,1 @@
-timeout 900 python bench.py --no-cpu-baseline 2>&1 | tail -1
+timeout 1200 python -m pytest tests -m gpu -q -x --timeout 600 2>&1 | tail -8

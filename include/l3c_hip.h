@@ -159,6 +159,15 @@ int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *t
 int l3c_dmll_nll(const float *P, const float *x, int64_t B, int64_t HW, int C, int K, int rgb, float x_min,
                  float x_max, int L, float *nll, l3c_stream_t stream);
 
+/*
+ * Sample from the mixture (DiscretizedMixLogisticLoss._non_shared_sample, logistic_mixture.py:277-323): component by
+ * Gumbel-max over the logits, value by the inverse logistic CDF; rgb: lambda coupling with the chosen components + clamp to
+ * [0, 255].  The uniforms are inputs (the reference draws them with uniform_(1e-5, 1 - 1e-5), :286, :300):
+ *   u_mix       fp32 planar [B][C][K][HW]        u_logistic  fp32 planar [B][C][HW]        x  fp32 planar [B][C][HW] (not rounded)
+ */
+int l3c_dmll_sample(const float *P, const float *u_mix, const float *u_logistic, int64_t B, int64_t HW, int C, int K,
+                    int rgb, float *x, l3c_stream_t stream);
+
 /* ---- convolution stack (replaces the cuDNN convs behind modules/{net,edsr,head,prob_clf}.py) ---------------------- */
 
 /*

@@ -56,6 +56,7 @@ PROTOTYPES = {
     'l3c_dmll_channel_params': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'l3c_cdf_table_mixture': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'l3c_dmll_encode_intervals': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'l3c_dmll_sample': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     'l3c_dmll_nll': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp]),
     'l3c_conv_packed_words': (c_i64, [c_int, c_int, c_int]),
     'l3c_conv_pack_weights': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),

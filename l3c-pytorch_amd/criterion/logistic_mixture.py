@@ -78,5 +78,14 @@ class DiscretizedMixLogisticLoss(nn.Module):
         x = x.to('cuda', torch.float32).contiguous()
         return ops.dmll_nll(ops.as_pixel_major(l), x, C, K, self.rgb_scale, self.x_min, self.x_max, self.L)
 
-    def sample(self, l, C):
-        raise NotImplementedError('sampling is out of scope of the hot path (SURVEY.md section 8f, item 4)')
+    def sample(self, l, C, noise=None):
+        """Sample from the model (reference _non_shared_sample :277-323): l (N,Kp,H,W) -> x (N,C,H,W) fp32, not rounded.
+        noise: (u_mix (N,C,K,H,W), u_logistic (N,C,H,W)) uniforms; default: drawn on the device like the reference does
+        (uniform_(1e-5, 1 - 1e-5), :286, :300)."""
+        N, Kp, H, W = l.shape
+        K = self._K(l, C)
+        if noise is None:
+            noise = (torch.empty(N, C, K, H, W, device='cuda').uniform_(1e-5, 1. - 1e-5),
+                     torch.empty(N, C, H, W, device='cuda').uniform_(1e-5, 1. - 1e-5))
+        u_mix, u_log = [u.to('cuda', torch.float32).contiguous() for u in noise]
+        return ops.dmll_sample(ops.as_pixel_major(l), u_mix, u_log, C, K, self.rgb_scale)

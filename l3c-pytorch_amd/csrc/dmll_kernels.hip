@@ -263,6 +263,55 @@ __global__ __launch_bounds__(256) void nll_kernel(const float *__restrict__ P, c
     }
 }
 
+// ---- sampling (DiscretizedMixLogisticLoss._non_shared_sample, logistic_mixture.py:277-323) ------------------------------------
+// One thread per pixel walks the C channels: component by Gumbel-max over the mixture logits (first maximum wins, as
+// torch.argmax), then the inverse logistic CDF of the chosen component; the RGB scale couples the channels through the
+// lambda coefficients OF THE COMPONENTS CHOSEN FOR G AND B and clamps to [0, 255] (:305-322).  The uniforms are inputs, so
+// the kernel is a pure function (and comparable with the oracle).
+__global__ __launch_bounds__(256) void sample_kernel(const float *__restrict__ P, const float *__restrict__ u_mix,
+                                                     const float *__restrict__ u_log, int64_t HW, int C, int K, int rgb,
+                                                     float *__restrict__ x_out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const int CK = C * K;
+    const int ld = Kp + 1;
+    const int64_t b = blockIdx.y;
+    const int64_t pix0 = (int64_t)blockIdx.x * kHeadPix;
+    const int npix = (int)((HW - pix0) < kHeadPix ? (HW - pix0) : kHeadPix);
+    const int tid = threadIdx.x;
+    const float *src = P + (b * HW + pix0) * Kp;
+    for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+    __syncthreads();
+    for (int p = tid; p < npix; p += 256) {
+        const float *px = tile + p * ld;
+        const int64_t n = pix0 + p;
+        float xs[3] = {0.f, 0.f, 0.f};
+        for (int c = 0; c < C; ++c) {
+            int sel = 0;
+            float best = -INFINITY;
+            for (int k = 0; k < K; ++k) {
+                const float u = u_mix[((b * C + c) * K + k) * HW + n];
+                const float g = px[c * K + k] - logf(-logf(u));
+                if (g > best) {
+                    best = g;
+                    sel = k;
+                }
+            }
+            const float mu = px[CK + c * K + sel];
+            const float ls = fmaxf(px[2 * CK + c * K + sel], kLogScalesMin);
+            const float u = u_log[(b * C + c) * HW + n];
+            float x = mu + expf(ls) * (logf(u) - logf(1.0f - u));
+            if (rgb) {
+                if (c == 1) x = x + sigmoid_f(px[3 * CK + sel]) * xs[0];
+                if (c == 2) x = (x + sigmoid_f(px[3 * CK + K + sel]) * xs[0]) + sigmoid_f(px[3 * CK + 2 * K + sel]) * xs[1];
+                x = fminf(fmaxf(x, 0.0f), 255.0f);
+                xs[c] = x;
+            }
+            x_out[(b * C + c) * HW + n] = x;
+        }
+    }
+}
+
 int grid_1d(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
     return (int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -329,5 +378,19 @@ int l3c_dmll_nll(const float *P, const float *x, int64_t B, int64_t HW, int C, i
     hipLaunchKernelGGL(nll_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, x, HW, C, K, rgb, x_lower, x_upper,
                        (float)(bin / 2.0), nll);
     return l3c::check_launch("nll_kernel");
+}
+
+int l3c_dmll_sample(const float *P, const float *u_mix, const float *u_logistic, int64_t B, int64_t HW, int C, int K,
+                    int rgb, float *x, l3c_stream_t stream) {
+    L3C_REQUIRE(P && u_mix && u_logistic && x, "null pointer");
+    L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0, "bad shape");
+    L3C_REQUIRE(K > 0 && K <= kMaxK, "K out of range (1..16)");
+    L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const size_t lds = (size_t)kHeadPix * (Kp + 1) * sizeof(float);
+    L3C_REQUIRE(lds <= 64 * 1024, "Kp too large for the LDS tile");
+    const dim3 grid((unsigned)((HW + kHeadPix - 1) / kHeadPix), (unsigned)B);
+    hipLaunchKernelGGL(sample_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, u_mix, u_logistic, HW, C, K, rgb, x);
+    return l3c::check_launch("sample_kernel");
 }
 }

@@ -312,8 +312,68 @@ class MultiscaleNetwork(nn.Module):
             raise ValueError('Expected BCHW image, got {}'.format(tuple(x.shape)))
         return x.to('cuda', torch.float32).contiguous()
 
-    def sample_forward(self, *a, **kw):
-        raise NotImplementedError('sampling is out of scope of the hot path (SURVEY.md section 8f, item 4)')
+    # -- sampling (reference :328-406) ------------------------------------------------------------------------------------
+
+    def sample_forward(self, x, losses, sample_scales, partial_final=None, auto_recurse=0, draw=None):
+        """x: image NCHW in [0, 255] -> sampled image (N,3,H,W) fp32 in [0, 255], not rounded.
+        The image is encoded; the decoders then run coarse -> fine and are fed the encoder's z^(s+1) or -- for the scales in
+        `sample_scales` -- values SAMPLED from the coarser scale's predicted mixture (continuous, as in the reference);
+        the finest prediction is always sampled.  If the coarsest scale is in `sample_scales` its input is drawn from the
+        uniform prior and quantised.
+        draw(shape, lo, hi) -> uniforms (any device); default: torch.empty(shape, device='cuda').uniform_(lo, hi).  The
+        draws are requested in the reference's order, so a seeded host generator reproduces its noise."""
+        if auto_recurse != 0:
+            raise NotImplementedError('Currently not supported for sampling: autorecurse={}'.format(auto_recurse))
+        if self._rgb:
+            raise NotImplementedError('sampling is implemented for the L3C configuration')
+        _lib.require_gpu()
+        if draw is None:
+            draw = lambda shape, lo, hi: torch.empty(shape, device='cuda').uniform_(lo, hi)   # noqa: E731
+        print('-' * 40)
+        print('- Sampling {}'.format(sample_scales))
+        print('-' * 40)
+        x = self._as_device_image(x)
+        pk = self._prepare()
+        inp = ops.rgb_head(x, pk['ms1'][0], pk['ms1'][1], pk['ms2'][0], pk['ms2'][1], pk['head0'][0], pk['head0'][1])
+        enc = []
+        for s in range(self.scales):
+            if s:
+                inp = ops.conv(enc[-1][0], pk['heads'][s])
+            enc.append(self._encoder(inp, s, pk))
+        Cs = [3] + [e[2].shape[1] for e in enc]
+        prev_x, fuse = None, None
+        for s in reversed(range(self.scales)):
+            loss_dmm = losses.loss_dmol_rgb if s == 0 else losses.loss_dmol_n
+            if s in sample_scales:
+                if prev_x is None:
+                    print('Sampling uniformly!')
+                    fake = draw(tuple(enc[-1][2].shape), -1, 1).to('cuda', torch.float32)
+                    prev_x = self.quantize_x(fake, self.scales - 1)
+                    if partial_final:
+                        print('partial sampling')
+                        for c in partial_final:
+                            prev_x[:, c, ...] = enc[s][2][:, c, ...]
+                print('{}: Feeding sampled to decoder'.format(s))
+                dec_in = prev_x
+            else:
+                print('{}: Feeding encoder output to decoder'.format(s))
+                dec_in = enc[s][2]
+            fuse = self._decoder(dec_in.contiguous(), fuse, s, pk)
+            P = self._prob(fuse, s, pk)
+            if s == 0 or s - 1 in sample_scales:
+                C = Cs[s]
+                print('{}: sampling N{}HW for next scale'.format(s, C))
+                B, H, W, Kp = P.shape
+                K = Kp // ((4 if s == 0 else 3) * C)
+                noise = (draw((B, C, K, H, W), 1e-5, 1. - 1e-5), draw((B, C, H, W), 1e-5, 1. - 1e-5))
+                prev_x = loss_dmm.sample(P.permute(0, 3, 1, 2), C, noise=noise)
+        return prev_x
+
+    def quantize_x(self, x, scale):
+        """EDSRLikeEnc.quantize_x (net.py:132-134): x (N,C,H,W) -> levels[argmin_l (x - levels_l)^2] of that scale's quantiser."""
+        levels = self._prepare()['enc'][scale]['levels']
+        d = (x.to('cuda', torch.float32).unsqueeze(-1) - levels) ** 2
+        return levels[torch.min(d, dim=-1)[1]]
 
 
 def schema_levels_check(sd, cfg):

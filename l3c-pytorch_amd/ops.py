@@ -211,6 +211,16 @@ def dmll_nll(P_nhwc, x, C, K, rgb, x_min, x_max, L):
     return out
 
 
+def dmll_sample(P_nhwc, u_mix, u_log, C, K, rgb):
+    """P (B,H,W,Kp); u_mix (B,C,K,H,W), u_log (B,C,H,W) uniforms in (0,1) -> x fp32 (B,C,H,W), not rounded."""
+    B, H, W, _ = P_nhwc.shape
+    assert tuple(u_mix.shape) == (B, C, K, H, W) and tuple(u_log.shape) == (B, C, H, W), (u_mix.shape, u_log.shape)
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=P_nhwc.device)
+    call('l3c_dmll_sample', ptr(P_nhwc, torch.float32), ptr(u_mix, torch.float32), ptr(u_log, torch.float32), B, H * W, C, K,
+         int(rgb), ptr(out), stream())
+    return out
+
+
 # ---- arithmetic coder -------------------------------------------------------------------------------------------------
 
 

@@ -139,6 +139,36 @@ class DecodeError(Exception):
     pass
 
 
+class ImageSaver(object):
+    """test/image_saver.py:28-60: tensors with values in 0..255 (1CHW / CHW; truncated to uint8 like the reference's
+    `.type(torch.uint8)`) -> PNG files in one directory."""
+
+    def __init__(self, out_dir):
+        self.out_dir = out_dir
+        os.makedirs(self.out_dir, exist_ok=True)
+        self.saved_fs = []
+
+    def __str__(self):
+        return 'ImageSaver({})'.format(self.out_dir)
+
+    def save_img(self, img, filename):
+        img = img.detach().to('cpu').type(torch.uint8)
+        if img.dim() == 4:
+            assert img.shape[0] == 1, img.shape
+            img = img[0]
+        out_p = self.get_save_p(filename)
+        Image.fromarray(np.ascontiguousarray(img.permute(1, 2, 0).numpy())).save(out_p)
+        return out_p
+
+    def get_save_p(self, file_name):
+        self.saved_fs.append(file_name)
+        return os.path.join(self.out_dir, file_name)
+
+    def file_starting_with_exists(self, prefix):
+        import glob
+        return len(glob.glob(os.path.join(self.out_dir, prefix) + '*')) > 0
+
+
 class MultiscaleTester(object):
     def __init__(self, log_date, flags, restore_itr, l3c=False, configs_dir=None):
         """flags needs `.log_dir`; optional `.compare_theory`."""
@@ -232,7 +262,37 @@ class MultiscaleTester(object):
         conv = torch.tensor([np.log(2.) * n for n in num_subpixels_before_pad], dtype=torch.float64, device=nats.device)
         return (nats.double() / conv).cpu().numpy()
 
+    def _test_sample(self, testset):
+        """--sample OUT_DIR (reference :276-282, :327-328, :436-448): per image the ground truth and three sampled images --
+        RGB only, RGB + z1, RGB + z1 + z2 -- named with the bpsp of the scales that were NOT sampled."""
+        test_result = TestResult('bpsp')
+        image_saver = ImageSaver(os.path.join(self.flags.sample, self.log_date))
+        print('Will store samples in {}.'.format(image_saver.out_dir))
+        for i, img_p in enumerate(testset.ps):
+            filename = os.path.splitext(os.path.basename(img_p))[0]
+            raw = self._load_uint8(img_p).unsqueeze(0)
+            img_batch = MultiscaleBlueprint.pad(raw, self._padding_fac()).to('cuda', torch.float32)
+            out = self.blueprint.forward(img_batch)
+            loss_out = self.blueprint.get_loss(out, num_subpixels_before_pad=int(np.prod(raw.shape)))
+            test_result[filename] = float(sum(loss_out.nonrecursive_bpsps))
+            self._sample([float(b) for b in loss_out.nonrecursive_bpsps], img_batch, image_saver, '{}_{}'.format(i, filename))
+            print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+        return test_result
+
+    def _sample(self, bpsps, img_batch, image_saver, save_prefix):
+        if image_saver.file_starting_with_exists(save_prefix):
+            raise FileExistsError('Previous sample outputs found in {}. Please remove.'.format(image_saver.out_dir))
+        image_saver.save_img(img_batch, '{}_{:.3f}_gt.png'.format(save_prefix, sum(bpsps)))
+        for style, sample_scales in (('rgb', []),               # sample the RGB scale only
+                                     ('rgb+bn0', [0]),          # RGB + z^(1)
+                                     ('rgb+bn0+bn1', [0, 1])):  # RGB + z^(1) + z^(2)
+            sampled = self.blueprint.sample_forward(img_batch, sample_scales)
+            bpsp_sample = sum(bpsps[len(sample_scales) + 1:])
+            image_saver.save_img(sampled, '{}_{}_{:.3f}.png'.format(save_prefix, style, bpsp_sample))
+
     def _test(self, testset):
+        if getattr(self.flags, 'sample', None):
+            return self._test_sample(testset)
         test_result = TestResult('bpsp recursive' if self.recursive else 'bpsp')
         # every auto-crop of every image, grouped by padded shape so that equal shapes share one forward
         items, groups = [], collections.defaultdict(list)

@@ -4,6 +4,7 @@ Restates criterion/logistic_mixture.py of the reference for the non-shared head 
   params_for_channel  <- _extract_non_shared_c :248-275 + cdf_step_non_shared :134-141 (WITHOUT the reference's
                          in-place write-through into `l`; callers here always pass the pristine P)
   nll                 <- forward :146-207 with _extract_non_shared :209-246, log_softmax :334-337, log_sum_exp :340-345
+  sample              <- _non_shared_sample :277-323, with the two uniform draws (:286, :300) as explicit inputs
   to_sym / to_bn      <- modules/quantizer.py:38-47
 Channel layout of P: index = p*(C*K) + c*K + k, p in {0: logit pi, 1: mu, 2: log sigma, 3: lambda (RGB only)}.
 """
@@ -90,3 +91,27 @@ def nll(spec, x, l):
     cond_c = (x < spec.x_min + 0.001).float()
     log_probs = cond_c * log_cdf_plus + (1. - cond_c) * out_b
     return -_log_sum_exp(log_probs + _log_softmax(logit, dim=2), dim=2)
+
+
+def sample(spec, l, C, u_mix, u_log):
+    """l (N,Kp,H,W); u_mix (N,C,K,H,W), u_log (N,C,H,W): the uniforms the reference draws with uniform_(1e-5, 1 - 1e-5).
+    -> x (N,C,H,W) float, not rounded (the RGB scale is clamped to [0, 255])."""
+    N, Kp, H, W = l.shape
+    K = Kp // (spec.num_params * C)
+    l = l.reshape(N, spec.num_params, C, K, H, W)
+    sel = torch.argmax(l[:, 0] - torch.log(-torch.log(u_mix)), dim=2).unsqueeze(2)          # Gumbel-max over K
+    means = torch.gather(l[:, 1], 2, sel).squeeze(2)
+    log_scales = torch.clamp(torch.gather(l[:, 2], 2, sel).squeeze(2), min=LOG_SCALES_MIN)
+    x = means + torch.exp(log_scales) * (torch.log(u_log) - torch.log(1. - u_log))           # inverse logistic CDF
+    if spec.rgb:
+        assert C == 3
+        coeffs = torch.sigmoid(l[:, 3])                                                      # (N,3,K,H,W)
+        sel_g, sel_b = sel[:, 1], sel[:, 2]
+        g_r = torch.gather(coeffs[:, 0], 1, sel_g).squeeze(1)
+        b_r = torch.gather(coeffs[:, 1], 1, sel_b).squeeze(1)
+        b_g = torch.gather(coeffs[:, 2], 1, sel_b).squeeze(1)
+        x0 = torch.clamp(x[:, 0], 0, 255.)
+        x1 = torch.clamp(x[:, 1] + g_r * x0, 0, 255.)
+        x2 = torch.clamp(x[:, 2] + b_r * x0 + b_g * x1, 0, 255.)
+        x = torch.stack((x0, x1, x2), dim=1)
+    return x

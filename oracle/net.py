@@ -9,6 +9,7 @@ dec.skip, non-recursive):
   decoder             <- modules/net.py EDSRDec.forward :173-184, edsr.Upsampler :92-119 (conv 64->256 + PixelShuffle(2))
   prob_clf            <- modules/prob_clf.py StackedAtrousConvs.forward :71-74
   forward / get_P     <- modules/multiscale_network.py :226-246, :260-306, :308-322 (eval mode: decoders are fed bn_q)
+  sample_forward      <- modules/multiscale_network.py :328-406 (the uniform draws are delegated to a `draw` callable)
 The RGB baselines (BicubicSubsampling) are not restated here ("next").
 """
 from collections import namedtuple
@@ -103,6 +104,47 @@ def forward(img, sd, hp=L3C_HYPER):
 def get_P(scale, bn_q, dec_F_prev, sd, hp=L3C_HYPER):
     f = decoder(bn_q, dec_F_prev, sd, scale, hp)
     return prob_clf(f, sd, scale), f
+
+
+def default_draw(shape, lo, hi):
+    """The reference's draw: torch.zeros_like(t).uniform_(lo, hi) on the CPU generator (consumes it in the same order)."""
+    return torch.zeros(shape).uniform_(lo, hi)
+
+
+def sample_forward(img, sd, sample_scales, hp=L3C_HYPER, draw=default_draw, partial_final=None):
+    """multiscale_network.py:328-406: encode, then decode coarse -> fine feeding either the encoder's bn_q or the values
+    sampled from the coarser scale's prediction; returns the sampled RGB image (N,3,H,W) float in [0, 255], not rounded."""
+    from oracle import dmll
+    x = conv(img, sd, 'sub_rgb_mean')
+    encs, Cs = [], [3]
+    for s in range(hp.num_scales):
+        e = encoder(head(x, sd, s), sd, s, hp)
+        encs.append(e)
+        Cs.append(e.bn.shape[1])
+        x = e.F
+    prev_x, fuse = None, None
+    for s in reversed(range(hp.num_scales)):
+        spec = dmll.RGB if s == 0 else dmll.z_spec(hp.levels_range, hp.L)
+        if s in sample_scales:
+            if prev_x is None:
+                fake = draw(tuple(encs[-1].bn_q.shape), -1, 1)
+                prev_x, _ = quantise(fake, sd['nets.{}.enc.levels'.format(hp.num_scales - 1)])
+                if partial_final:
+                    for c in partial_final:
+                        prev_x[:, c] = encs[s].bn_q[:, c]
+            dec_in = prev_x
+        else:
+            dec_in = encs[s].bn_q
+        fuse = decoder(dec_in, fuse, sd, s, hp)
+        P = prob_clf(fuse, sd, s)
+        if s == 0 or s - 1 in sample_scales:
+            C = Cs[s]
+            N, Kp, H, W = P.shape
+            K = Kp // (spec.num_params * C)
+            u_mix = draw((N, C, K, H, W), 1e-5, 1. - 1e-5)
+            u_log = draw((N, C, H, W), 1e-5, 1. - 1e-5)
+            prev_x = dmll.sample(spec, P, C, u_mix, u_log)
+    return prev_x
 
 
 # ---- RGB baselines (BicubicSubsampling encoders; configs/ms/cr_rgb_shared.cf, cr_rgb.cf) ---------------------------------------

@@ -7,7 +7,8 @@
 
 Prints the mean bpsp of every (test set, experiment, iteration); results are cached in LOG_DIR_test/<experiment>/cache.pkl.
 `--write_to_files` encodes every image to DIR/<name>.l3c with the HIP coder, decodes it again and asserts equality.
-`--recursive auto|N` evaluates the RGB Shared baseline recursively; `--sample` (sampling path) is not on this build's hot path.
+`--recursive auto|N` evaluates the RGB Shared baseline recursively; `--sample OUT_DIR` stores sampled images (RGB, RGB+z1,
+RGB+z1+z2) next to the ground truth.
 """
 import argparse
 import os
@@ -54,8 +55,6 @@ def main(argv=None):
         raise ValueError('Cannot have --write_to_files and --sample.')
     if flags.time_report and not flags.write_to_files:
         raise ValueError('--time_report only valid with --write_to_files.')
-    if flags.sample:
-        raise NotImplementedError('sampling is out of scope of the hot path (SURVEY.md section 8f, item 4)')
 
     testsets = [Testset(s.rstrip('/'), flags.max_imgs_per_folder, append_id='_crop{}'.format(flags.crop) if flags.crop else None)
                 for s in flags.images.split(',')]

@@ -8,6 +8,9 @@ modules imported through oracle/ref_import.py) on seeded inputs that the tests c
   ac_kat.npz     range coder:   torchac_backend_cpu.encode_cdf / decode_cdf (torchac.cpp:263-269, :424-430)
   cdf_kat.npz    CDF tables:    torchac._get_uint16_cdf (torchac.py:174-178), Bitcoding._get_uniform_cdf (bitcoding.py:206-210)
   net_rgb_32x48.npz  RGB baselines (cr_rgb_shared with auto_recurse=3, cr_rgb): S pyramids (PIL bicubic), P, bpsp
+  sample_32.npz  sampling:      MultiscaleBlueprint.sample_forward (multiscale_network.py:328-406) with the CPU generator seeded,
+                                for the sample_scales the reference's tester uses ([], [0], [0, 1]; multiscale_tester.py:443-445)
+                                and [0, 1, 2] (uniform prior on the coarsest scale)
   net_32.npz     config[0]:     MultiscaleBlueprint.forward / get_loss, DiscretizedMixLogisticLoss.cdf_step_non_shared,
                                 MultiscaleNetwork.get_P, Bitcoding.encode -> file bytes, Bitcoding.decode
                                 on one 32x32 image with the synthetic checkpoint (helpers/synthetic.py, seed 0)
@@ -250,6 +253,31 @@ def make_rgb_fixtures():
     np.savez_compressed(os.path.join(HERE, 'net_rgb_32x48.npz'), **out)
 
 
+def make_sample_fixture(H=32, W=32, seed=0, img_seed=3):
+    """The draws come from torch's CPU generator: torch.manual_seed(SEED) immediately before the call, so a restatement that
+    draws tensors of the same shapes in the same order (oracle.net.default_draw) sees the same uniforms."""
+    cfg_mine = config_parser.parse_builtin('ms', 'cr')
+    sd = synthetic.make_state_dict(cfg_mine, seed)
+    img = synthetic.make_image(H, W, img_seed, 'natural').unsqueeze(0).long()
+    out = {'img': img.numpy().astype(np.uint8)}
+    with ref_import.reference_modules():
+        from fjcommon import config_parser as rcp
+        from blueprints.multiscale_blueprint import MultiscaleBlueprint
+        cfg, _ = rcp.parse('configs/ms/cr.cf')
+        bp = MultiscaleBlueprint(cfg)
+        bp.net.load_state_dict(sd, strict=True)
+        bp.set_eval()
+        with torch.no_grad():
+            for i, scales in enumerate(([], [0], [0, 1], [0, 1, 2])):
+                torch.manual_seed(100 + i)
+                x = bp.sample_forward(img.float(), scales)
+                out['scales%d' % i] = np.array(scales, dtype=np.int64)
+                out['seed%d' % i] = np.array(100 + i)
+                out['x%d' % i] = x.numpy().copy()
+                print('  sample', scales, tuple(x.shape), float(x.min()), float(x.max()))
+    np.savez_compressed(os.path.join(HERE, 'sample_32.npz'), **out)
+
+
 def main():
     with ref_import.reference_modules():
         import torchac_backend_cpu
@@ -264,6 +292,8 @@ def main():
     make_net_fixture()
     print('RGB baseline fixtures')
     make_rgb_fixtures()
+    print('sampling fixture')
+    make_sample_fixture()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

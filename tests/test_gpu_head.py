@@ -124,3 +124,27 @@ def test_nll_edge_symbols():
     got = ops.dmll_nll(P.cuda(), x.cuda(), 3, 10, True, 0, 255, 256).cpu()
     ref = odmll.nll(odmll.RGB, x, P.permute(0, 3, 1, 2).contiguous())
     assert torch.allclose(got, ref, rtol=2e-5, atol=2e-5), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize('rgb,C,H,W', [(True, 3, 9, 13), (False, 5, 16, 24), (True, 3, 64, 70)])
+def test_sample_kernel_vs_oracle(rgb, C, H, W):
+    """l3c_dmll_sample vs the oracle's restatement of _non_shared_sample on identical P and identical uniforms.  fp32 with
+    device log/exp: values within 2e-3 absolute (values reach 255, the logistic tail multiplies log errors by sigma <= e^2)
+    wherever both picked the same mixture component; the Gumbel-max may flip where the two best candidates are within
+    rounding of each other -- tolerated on < 0.1 % of the pixel-channels."""
+    from l3c_pytorch_amd import ops
+    rng = np.random.RandomState(H * W)
+    B, K = 2, 10
+    P = _rand_P(rng, B, H, W, C, K, rgb)
+    u_mix = rng.uniform(1e-5, 1 - 1e-5, size=(B, C, K, H, W)).astype(np.float32)
+    u_log = rng.uniform(1e-5, 1 - 1e-5, size=(B, C, H, W)).astype(np.float32)
+    got = ops.dmll_sample(torch.from_numpy(P).cuda(), torch.from_numpy(u_mix).cuda(), torch.from_numpy(u_log).cuda(),
+                          C, K, rgb).cpu()
+    spec = odmll.RGB if rgb else odmll.z_spec()
+    want = odmll.sample(spec, torch.from_numpy(P).permute(0, 3, 1, 2).contiguous(), C, torch.from_numpy(u_mix),
+                        torch.from_numpy(u_log))
+    assert got.shape == want.shape == (B, C, H, W)
+    bad = ((got - want).abs() > 2e-3).float().mean().item()
+    assert bad < 1e-3, bad
+    if rgb:
+        assert got.min() >= 0 and got.max() <= 255

@@ -244,6 +244,16 @@ def test_test_py_driver_bpsp_cache_and_write_to_files(synthetic_l3c, tmp_path, c
     cli.main([str(tmp_path / 'logs'), '0306_0001', str(imgs_dir), '--write_to_files', str(out_dir), '--time_report', str(report)])
     assert sorted(os.listdir(str(out_dir))) == ['a.l3c', 'b.l3c', 'c.l3c']
     assert 'bc.encode' in report.read_text() and 'bc.decode' in report.read_text()
+    # --sample (reference multiscale_tester.py:436-448): ground truth + 3 sampled images per input, refuses to overwrite
+    samples = tmp_path / 'samples'
+    cli.main([str(tmp_path / 'logs'), '0306_0001', str(imgs_dir), '--sample', str(samples), '--overwrite_cache'])
+    files = sorted(os.listdir(str(samples / '0306_0001')))
+    assert len(files) == 12 and sum(f.endswith('_gt.png') for f in files) == 3, files
+    assert {f.split('_')[2] for f in files if not f.endswith('_gt.png')} == {'rgb', 'rgb+bn0', 'rgb+bn0+bn1'}
+    gt = np.array(Image.open(str(samples / '0306_0001' / [f for f in files if f.startswith('2_c') and f.endswith('_gt.png')][0])))
+    assert gt.shape == (32, 48, 3)       # the 27x41 image, padded to a multiple of 8 like the tester's forward
+    with pytest.raises(FileExistsError):
+        cli.main([str(tmp_path / 'logs'), '0306_0001', str(imgs_dir), '--sample', str(samples), '--overwrite_cache'])
 
 
 def test_bicubic_encoder_is_pillow_exact():
@@ -292,3 +302,32 @@ def test_rgb_baselines_forward_and_loss_vs_reference_fixture(golden, name, recur
         assert np.allclose([float(b) for b in loss.recursive_bpsps], g[name + '/recursive_bpsps'], rtol=2e-3)
     else:
         assert loss.recursive_bpsps is None
+
+
+def test_sample_forward_vs_oracle_with_the_same_draws(golden, blueprint, synthetic_l3c):
+    """sample_forward with a seeded host generator as `draw` requests its uniforms in the reference's order, so the
+    oracle (pinned on the reference's own sample_forward by tests/test_oracle.py) sees the same noise.  Sampling only the
+    RGB scale keeps every decision local to a pixel: all but a few values must agree; deeper sampling cascades any flipped
+    mixture choice through the decoders, so there only shape / range / determinism are checked."""
+    from oracle import net as onet
+    g = golden('sample_32.npz')
+    _, sd = synthetic_l3c
+    img = torch.from_numpy(g['img'].astype(np.float32))
+    draw = lambda shape, lo, hi: torch.zeros(shape).uniform_(lo, hi)   # noqa: E731
+    torch.manual_seed(5)
+    got = blueprint.net.sample_forward(img, blueprint.losses, [], draw=draw).cpu()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        want = onet.sample_forward(img, sd, [])
+    assert got.shape == want.shape == (1, 3, 32, 32)
+    assert ((got - want).abs() > 1e-2).float().mean() < 0.01
+    for scales in ([0], [0, 1], [0, 1, 2]):
+        torch.manual_seed(6)
+        a = blueprint.net.sample_forward(img, blueprint.losses, scales, draw=draw)
+        torch.manual_seed(6)
+        b = blueprint.net.sample_forward(img, blueprint.losses, scales, draw=draw)
+        assert a.shape == (1, 3, 32, 32) and torch.equal(a, b)
+        assert a.min() >= 0 and a.max() <= 255
+    # device-side draws (the default) work and differ from call to call
+    c, d = blueprint.sample_forward(img, [0]), blueprint.sample_forward(img, [0])
+    assert c.is_cuda and not torch.equal(c, d)

@@ -240,3 +240,20 @@ def test_pil_resample_emulation_is_pillow_exact():
         ref = np.array(Image.fromarray(img).resize((ow, oh), Image.BICUBIC))
         got = pr.resample_u8_numpy(img.transpose(2, 0, 1), oh, ow).transpose(1, 2, 0)
         assert np.array_equal(ref, got), (H, W)
+
+
+def test_sampling_oracle_matches_reference_fixture(golden, synthetic_l3c):
+    """sample_forward restatement vs the reference's own sample_forward: same seed -> same draws (oracle.net.default_draw
+    consumes the CPU generator like the reference) -> same image, for every sample_scales of the fixture."""
+    from oracle import net as onet
+    g = golden('sample_32.npz')
+    _, sd = synthetic_l3c
+    img = torch.from_numpy(g['img'].astype(np.float32))
+    with torch.no_grad():
+        for i in range(4):
+            torch.manual_seed(int(g['seed%d' % i]))
+            x = onet.sample_forward(img, sd, [int(v) for v in g['scales%d' % i]])
+            ref = torch.from_numpy(g['x%d' % i])
+            assert x.shape == ref.shape
+            close = (x - ref).abs() <= 1e-3
+            assert close.float().mean() > 0.999, (i, float((x - ref).abs().max()), float(close.float().mean()))
