@@ -65,7 +65,8 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         e0.record()
         call('l3c_conv_mfma', d, stream())
         e1.record()
-        key = 'conv_mfma<k{},s{},d{}>'.format(layer.KS, layer.stride, layer.dilation)
+        key = ('conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
+               'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
         PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, e0, e1))
         return out
     call('l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
