@@ -101,7 +101,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    # launched by torch.distributed.run (any world size, 1 included): RCCL for the barrier and the max-over-ranks time
+    distributed = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
+    if distributed:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
@@ -126,7 +128,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -142,7 +144,7 @@ def main():
     elapsed = time.perf_counter() - t0
     records, ops.PROFILE = ops.PROFILE, None
 
-    if world > 1:
+    if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -200,7 +202,7 @@ def main():
             'roofline': roofline, 'cpu_baseline': cpu, 'decode': decode,
         }
         print(json.dumps(result))
-    if world > 1:
+    if distributed:
         dist.barrier()
         dist.destroy_process_group()
     return result

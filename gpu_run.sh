@@ -1,7 +1,3 @@
-cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_c -o bench -- python $R/bench.py > $R/gpurun_out/bench_prof.json 2> $R/gpurun_out/bench_prof.err
-cd $R
-python tools/rocpd_summary.py gpurun_out/prof_c/bench_results.db gpurun_out/r01_c_kernel_stats.csv 2>&1 | head -16
-tail -1 gpurun_out/bench_prof.json
-timeout 600 python bench.py > gpurun_out/bench_plain.json 2>gpurun_out/bench_plain.err; tail -1 gpurun_out/bench_plain.json
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-decode 2>&1 | tail -2 | cut -c1-400
+timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29512 tools/bench_dataset.py --images 16 2>&1 | tail -3

@@ -277,7 +277,7 @@ struct Geo3 {
 };
 
 template <int KS, int DIL, int CK_, int WN_>
-__global__ __launch_bounds__(512, 2) void conv_lds_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512, (CK_ <= 8 ? 4 : 2)) void conv_lds_kernel(const ConvParams p) {
     using G = Geo3<KS, DIL, CK_, WN_>;
     constexpr int MT = G::MT, CK = G::CK, GPC = G::GPC, NSTEPS = G::TAPS * GPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -620,6 +620,7 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
         const int dbg = (d->epilogue >> 8) & 3;
         return dbg == 1 ? launch<3, 1, 1, 16, 2, 1>(p, s) : dbg == 2 ? launch<3, 1, 1, 16, 2, 2>(p, s) : launch<3, 1, 1, 16, 2, 3>(p, s);
     }
+    if (d->KS == 3 && d->dilation == 1 && (d->epilogue & 4096)) return launch_lds<3, 1, 8, 1>(p, s);   // probe: 2 blocks per CU
     if (d->KS == 3 && d->dilation == 1) return (d->epilogue & 2048) ? launch<3, 1, 1, 16, 2>(p, s) : launch_lds<3, 1>(p, s);
     if (d->KS == 3 && d->dilation == 2) return (d->epilogue & 2048) ? launch<3, 1, 2, 16, 2>(p, s) : launch_lds<3, 2>(p, s);
     if (d->KS == 3 && d->dilation == 4) return (d->epilogue & 2048) ? launch<3, 1, 4, 16, 2>(p, s) : launch_lds<3, 4>(p, s);

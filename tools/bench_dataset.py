@@ -5,7 +5,7 @@ image encoded END TO END: host uint8 image -> H2D -> pad -> forward -> fused hea
 host memory.  Images of equal padded shape share a batch; ONE grouped range-coder launch (l3c_ac_encode_groups) then codes every
 stream of every batch concurrently.
 
-    python tools/bench_dataset.py [--n 64] [--max-batch 16]
+    python tools/bench_dataset.py [--images 64] [--max-batch 16]
     python -m torch.distributed.run --nproc-per-node N tools/bench_dataset.py ...     (one process per GPU, RCCL for the stats)
 """
 import argparse
@@ -43,7 +43,7 @@ def draw_sizes(n, seed=0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--n', type=int, default=64)
+    ap.add_argument('--images', dest='n', type=int, default=64)
     ap.add_argument('--max-batch', type=int, default=16)
     ap.add_argument('--per-batch-coder', action='store_true', help='one coder launch per batch instead of one grouped launch')
     a = ap.parse_args()
