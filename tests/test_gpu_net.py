@@ -331,3 +331,30 @@ def test_sample_forward_vs_oracle_with_the_same_draws(golden, blueprint, synthet
     # device-side draws (the default) work and differ from call to call
     c, d = blueprint.sample_forward(img, [0]), blueprint.sample_forward(img, [0])
     assert c.is_cuda and not torch.equal(c, d)
+
+
+def test_reference_per_channel_api_produces_the_batched_files_payloads(blueprint):
+    """coders.ArithmeticCoder + coders_helpers.CodingCDFNonshared -- the reference's per-scale, per-channel loop
+    (bitcoding.py:171-232) written against our mirrors -- yields byte-for-byte the payloads of the batched encoder, and
+    range_decode inverts them."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.bitcoding.coders import ArithmeticCoder
+    from l3c_pytorch_amd.bitcoding.coders_helpers import CodingCDFNonshared
+    from l3c_pytorch_amd.helpers import synthetic
+    img = synthetic.make_image(32, 48, 21, 'natural').unsqueeze(0).long()
+    bc = Bitcoding(blueprint)
+    out = blueprint.forward(img.float())
+    payloads = bc.encode_batch(img, out=out).payloads()          # coarse -> fine, [scale][b][c]
+    for k, (scale, dmll, uniform) in enumerate(bc.iter_scale_dmll()):
+        if uniform:
+            continue
+        S, C = out.S[scale], out.S[scale].shape[1]
+        x = img.float().cuda() if scale == 0 else out.bn[scale]
+        helper = CodingCDFNonshared(out.P[scale], total_C=C, dmll=dmll)
+        coder = ArithmeticCoder(dmll.L)
+        for c in range(C):
+            cdf = helper.get_next_C(x)
+            data = coder.range_encode(S[:, c].to(torch.int16), cdf)
+            assert data == payloads[k][0][c], (scale, c, len(data), len(payloads[k][0][c]))
+            back = coder.range_decode(data, cdf)
+            assert torch.equal(back.long(), S[:, c].cpu().long())
