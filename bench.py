@@ -77,7 +77,8 @@ def cpu_baseline(sd, synthetic):
 def decode_leg(bc, enc, imgs, compute_stream):
     """Secondary figure (SURVEY.md section 8d "also decode MPix/s"), outside the timed region: decode the last coded batch
     back from its `.l3c` byte strings (host) to pixels in HBM and check it is lossless.  The range decoder is a serial
-    chain per stream (one wavefront each), so the time hardly depends on the batch size."""
+    chain per stream (one wavefront each; the R, G, B chains of an image run a chunk of pixels apart), so the time depends
+    little on the batch size."""
     SYMBOLS_PER_PX = 4.640625           # 3 P0 + 5 (P1 + P2 + P3) symbols per image pixel, SURVEY.md section 8d
     with torch.cuda.stream(compute_stream):
         files = enc.to_bytes()
@@ -90,8 +91,9 @@ def decode_leg(bc, enc, imgs, compute_stream):
     B = len(files)
     return {'value': round(B * H * W / 1e6 / dt, 3), 'unit': 'MPix/s', 'batch': B, 'seconds': round(dt, 3),
             'lossless': lossless, 'msym_per_s_aggregate': round(B * H * W * SYMBOLS_PER_PX / 1e6 / dt, 1),
-            'longest_chain_symbols': 3 * H * W,
-            'note': 'host .l3c bytes -> pixels in HBM; latency-bound: 3 x {} serial symbols per image (R -> G -> B)'.format(H * W)}
+            'longest_chain_symbols': H * W,
+            'note': 'host .l3c bytes -> pixels in HBM; latency-bound: serial chains of {} symbols per RGB channel, the three '
+                    'channels pipelined a chunk of pixels apart'.format(H * W)}
 
 
 def main():

@@ -117,6 +117,35 @@ int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t
                   l3c_stream_t stream);
 
 /* flag_out[0] |= 1 when some row of the table is not strictly increasing over entries [0, Lp-2]. */
+/*
+ * Chunked, grouped form of l3c_ac_decode for streams whose tables become available piecewise (the RGB scale: the table of G
+ * at a pixel needs R decoded at that pixel, logistic_mixture.py:262-272).  Each part decodes symbols [sym_offset, sym_offset +
+ * n_sym) of its streams from the table rows of exactly that range, resuming from / saving the coder state; the 1..8 parts
+ * of a call are independent and run side by side in ONE launch pair (R chunk j+2, G chunk j+1, B chunk j of a pipeline step).
+ *   cdf                [n_streams][n_sym][Lp] rows of THIS chunk
+ *   not_monotone_flag  device int32 (as written by l3c_cdf_check_monotone / l3c_dmll_cdf_table), read by the kernel -- no host
+ *                      synchronisation; null: the table is treated as not validated (reference's literal search)
+ *   state_in / _out    [n_streams] x l3c_ac_decode_state_bytes(); state_in null = start of the streams; must differ
+ *   final_chunk        non-zero when the streams end with this chunk (their last symbol skips the update, torchac.cpp:335-337)
+ *   sym_out            stream s writes sym_out[s * sym_stride + sym_offset + i], i < n_sym
+ */
+typedef struct {
+    const uint16_t *cdf;
+    int Lp;
+    const uint8_t *in;
+    const int64_t *in_offsets;
+    const uint32_t *in_nbytes;
+    int64_t n_streams, n_sym;
+    const int32_t *not_monotone_flag;
+    const void *state_in;
+    void *state_out;
+    int final_chunk;
+    int16_t *sym_out;
+    int64_t sym_stride, sym_offset;
+} l3c_ac_decode_part;
+int64_t l3c_ac_decode_state_bytes(void);
+int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_stream_t stream);
+
 int l3c_cdf_check_monotone(const uint16_t *cdf, int64_t n_rows, int Lp, int32_t *flag_out, l3c_stream_t stream);
 
 /* ---- logistic-mixture head (replaces torchac_kernel.cu + criterion/logistic_mixture.py on the coding path) --------- */
@@ -141,6 +170,14 @@ int l3c_dmll_channel_params(const float *P, const int16_t *sym, int64_t B, int64
 int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu, const float *log_sigma,
                           int64_t n_img, int64_t HW, int K, int Lp, uint16_t *cdf, int32_t *not_monotone,
                           l3c_stream_t stream);
+
+/*
+ * Decoder, fused: the uint16 table rows of channel c for pixels [pix0, pix0 + npix) of every image, straight from P and the
+ * symbols of the channels decoded so far (l3c_dmll_channel_params + l3c_cdf_table_mixture in one pass; identical entries).
+ *   cdf [B][npix][Lp];  not_monotone: optional flag, set (never cleared) if a row is not strictly increasing
+ */
+int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
+                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, l3c_stream_t stream);
 
 /*
  * Fused encoder head: straight from the network output P and the symbols to the packed coding intervals of every

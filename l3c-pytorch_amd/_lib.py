@@ -35,6 +35,13 @@ class AcGroup(ctypes.Structure):
                 ('n_streams', c_i64), ('n_sym', c_i64), ('out_stride_bytes', c_i64)]
 
 
+class AcDecodePart(ctypes.Structure):
+    """l3c_ac_decode_part (include/l3c_hip.h)."""
+    _fields_ = [('cdf', c_vp), ('Lp', c_int), ('in_', c_vp), ('in_offsets', c_vp), ('in_nbytes', c_vp),
+                ('n_streams', c_i64), ('n_sym', c_i64), ('not_monotone_flag', c_vp), ('state_in', c_vp),
+                ('state_out', c_vp), ('final_chunk', c_int), ('sym_out', c_vp), ('sym_stride', c_i64), ('sym_offset', c_i64)]
+
+
 EPI_RELU, EPI_RESIDUAL, EPI_PIXEL_SHUFFLE = 1, 2, 4
 
 # name -> (restype, argtypes); must list every symbol include/l3c_hip.h declares (tests/test_abi.py checks)
@@ -51,11 +58,14 @@ PROTOTYPES = {
     'l3c_ac_encode': (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'l3c_ac_encode_groups_workspace_bytes': (c_i64, [c_int, c_i64]),
     'l3c_ac_encode_groups': (c_int, [ctypes.POINTER(AcGroup), c_int, c_vp, c_vp]),
+    'l3c_ac_decode_state_bytes': (c_i64, []),
+    'l3c_ac_decode_chunks': (c_int, [ctypes.POINTER(AcDecodePart), c_int, c_vp]),
     'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),
     'l3c_cdf_check_monotone': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp]),
     'l3c_dmll_channel_params': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'l3c_cdf_table_mixture': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'l3c_dmll_encode_intervals': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp]),
+    'l3c_dmll_cdf_table': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
     'l3c_dmll_sample': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     'l3c_dmll_nll': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp]),
     'l3c_conv_packed_words': (c_i64, [c_int, c_int, c_int]),

@@ -264,24 +264,61 @@ class Bitcoding(object):
                 P = ops.as_pixel_major(P)
                 targets = self._targets(dmll)
                 if dmll.rgb_scale:
-                    # R -> G -> B: channel c's means depend on the decoded values of channels < c
-                    sym = torch.zeros(B, C, H, W, dtype=torch.int16, device='cuda')
-                    for c in range(C):
-                        pi, mu, ls = ops.dmll_channel_params(P, sym, C, K, True, c)
-                        table, flag = ops.cdf_table_mixture(targets, pi, mu, ls)
-                        buf, offs, lens = ops.pack_streams(payloads[c::C])
-                        sym[:, c] = ops.ac_decode(table.reshape(B * H * W, -1), buf, offs, lens, B, H * W,
-                                                  int(flag.item()) == 0).reshape(B, H, W)
+                    sym = self._decode_rgb_pipelined(P, targets, payloads, B, C, K, H, W)
                 else:
-                    params = [ops.dmll_channel_params(P, None, C, K, False, c) for c in range(C)]
-                    pi, mu, ls = [torch.stack([p[i] for p in params], dim=1).reshape(B * C, K, H, W) for i in range(3)]
-                    table, flag = ops.cdf_table_mixture(targets, pi, mu, ls)
-                    buf, offs, lens = ops.pack_streams(payloads)
-                    sym = ops.ac_decode(table.reshape(B * C * H * W, -1), buf, offs, lens, B * C, H * W,
-                                        int(flag.item()) == 0).reshape(B, C, H, W)
+                    sym = self._decode_z_scale(P, targets, payloads, B, C, K, H, W)
             bn_prev = ops.sym_to_bn(sym, dmll.bin_width, dmll.x_min)
         assert bn_prev is not None
         return bn_prev.round().long(), padding
+
+    def _decode_z_scale(self, P, targets, payloads, B, C, K, H, W):
+        """A bottleneck scale: its C channels are independent given P, so the C tables (fused, straight from P) and one
+        grouped decoder launch handle them side by side; table validity is a device-side flag (no host synchronisation)."""
+        HW = H * W
+        sym = torch.empty(B, C, H, W, dtype=torch.int16, device='cuda')
+        flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+        parts = []
+        for c in range(C):
+            table = ops.dmll_cdf_table(P, None, targets, C, K, False, c, 0, HW, flag)
+            buf, offs, lens = ops.pack_streams(payloads[c::C])
+            parts.append(ops.ac_decode_part(table.reshape(B * HW, -1), buf, offs, lens, B, HW, flag, None, None, True,
+                                            sym, C * HW, c * HW))
+        for k in range(0, C, 8):
+            ops.ac_decode_chunks(parts[k:k + 8])
+        return sym
+
+    RGB_CHUNKS = 8
+
+    def _decode_rgb_pipelined(self, P, targets, payloads, B, C, K, H, W):
+        """The RGB scale: channel c's means depend on the decoded values of the channels < c AT THE SAME PIXEL
+        (logistic_mixture.py:262-272), so R, G and B are three serial chains of H*W symbols that only have to stay one
+        chunk of pixels apart.  Pipeline step t: channel c handles chunk t - c -- its table rows are built straight from P
+        and the symbols decoded so far (l3c_dmll_cdf_table), then ONE grouped launch (l3c_ac_decode_chunks) resumes the range
+        decoders of all active channels side by side.  Everything stays on the current stream; table validity is a
+        device-side flag, so nothing synchronises with the host.  Time: (chunks + 2) steps instead of 3 * chunks."""
+        HW = H * W
+        n_chunks = max(1, min(self.RGB_CHUNKS, HW // 4096))
+        step = -(-HW // n_chunks)
+        step = -(-step // 64) * 64                       # chunk boundaries on the 64-symbol store blocks
+        bounds = [(p0, min(step, HW - p0)) for p0 in range(0, HW, step)]
+        sym = torch.zeros(B, C, H, W, dtype=torch.int16, device='cuda')
+        packed = [ops.pack_streams(payloads[c::C]) for c in range(C)]
+        flags = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(C)]
+        states = [[ops.ac_decode_state(B), ops.ac_decode_state(B)] for _ in range(C)]
+        for t in range(len(bounds) + C - 1):
+            parts = []
+            for c in range(C):
+                j = t - c
+                if not 0 <= j < len(bounds):
+                    continue
+                p0, n = bounds[j]
+                table = ops.dmll_cdf_table(P, sym, targets, C, K, True, c, p0, n, flags[c])
+                buf, offs, lens = packed[c]
+                parts.append(ops.ac_decode_part(table.reshape(B * n, -1), buf, offs, lens, B, n, flags[c],
+                                                states[c][(j + 1) & 1] if j else None, states[c][j & 1],
+                                                j == len(bounds) - 1, sym, C * HW, c * HW + p0))   # image b, channel c
+            ops.ac_decode_chunks(parts)
+        return sym
 
     # ---- reference API: one image <-> one file -----------------------------------------------------------------------
 

@@ -424,20 +424,22 @@ struct WaveBits {
         }
         return w;
     }
-    __device__ __forceinline__ void init(const uint32_t *w, uint32_t n, int lane_, uint32_t lds_addr) {
+    // next0 / acc0 / nb0: where a previous chunk of the same stream stopped (0, 0, 0 = start of the stream)
+    __device__ __forceinline__ void init(const uint32_t *w, uint32_t n, int lane_, uint32_t lds_addr, uint32_t next0 = 0,
+                                         uint64_t acc0 = 0, int nb0 = 0) {
         words = w;
         nbytes = n;
         lane = lane_;
         lds = lds_addr;
-        base = 0;
-        request(0);
-        request(64);
+        base = next0 & ~63u;
+        request(base);
+        request(base + 64u);
         vm_wait<0>();
-        cur = pick_up(0);
+        cur = pick_up(base);
         age = 3;
-        acc = 0;
-        nb = 0;
-        next = 0;
+        acc = acc0;
+        nb = nb0;
+        next = next0;
     }
     __device__ __forceinline__ uint32_t take(int count) {   // next `count` (0..32) bits, MSB first; zeros past the end
         const uint32_t w = lane_read(cur, next - base);
@@ -624,16 +626,54 @@ __device__ __forceinline__ void lds_row_take(Regs<4> &row, const Regs<4> &pendin
                  : "v"(pending.a), "v"(pending.b), "v"(pending.c), "v"(pending.d));
 }
 
-// FAST = true: the loop holds only decode_symbol_fast; a stream that leaves the fast path is marked by the sentinel -1 in its
-// first output symbol and abandoned.  FAST = false: the generic decoder, run afterwards for marked streams only (`force` = 0)
-// or for every stream (`force` = 1: table not validated).
+// Coder state of one stream between two chunks of it (l3c_ac_decode_chunk); 32 bytes, opaque to the caller.
+struct DecodeState {
+    uint32_t low, high, value, next;
+    uint64_t acc;
+    int32_t nb;
+    uint32_t pad;
+};
+static_assert(sizeof(DecodeState) == 32, "l3c_ac_decode_state_bytes");
+
+struct DecodeArgs {
+    const uint16_t *cdf;           // rows of THIS chunk: [n_streams][n_sym][Lp]
+    int Lp;
+    int64_t table_bytes;
+    const uint8_t *in;
+    const int64_t *in_offsets;
+    const uint32_t *in_nbytes;
+    int64_t n_streams;
+    uint32_t n_sym;                // symbols of this chunk
+    int monotone;                  // host-side knowledge about the table (used when `flag` is null)
+    const int32_t *flag;           // device-side: != 0 -> table not validated (overrides `monotone`)
+    int force;                     // generic pass: decode every stream, not only the marked ones
+    int final_chunk;               // the stream ends with this chunk: its last symbol does not advance the state
+    const DecodeState *state_in;   // null: start of the stream
+    DecodeState *state_out;        // null: not needed
+    int16_t *sym_out;
+    int64_t sym_stride, sym_offset;   // stream s writes sym_out[s * sym_stride + sym_offset + i]
+};
+
+// FAST = true: the loop holds only decode_symbol_fast; a stream that leaves the fast path is marked by the sentinel -1 in the
+// chunk's first output symbol and abandoned (state_out untouched).  FAST = false: the generic decoder, run afterwards for
+// marked streams only, or for every stream when the table is not validated.
+// Up to 8 independent decode calls in one launch (blockIdx.y selects the part): the chunk-pipelined RGB decode runs the R, G
+// and B chunks of one pipeline step side by side without relying on several HIP streams reaching distinct hardware queues.
+struct DecodeArgsPack {
+    static constexpr int N = 8;
+    DecodeArgs part[N];
+};
+
 template <int NJ, bool FAST>
-__global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__restrict__ cdf, int Lp, int64_t table_bytes,
-                                                            const uint8_t *__restrict__ in,
-                                                            const int64_t *__restrict__ in_offsets,
-                                                            const uint32_t *__restrict__ in_nbytes, uint32_t n_sym,
-                                                            int monotone, int force, int16_t *__restrict__ sym_out) {
+__global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack pack) {
     using C = RingCfg<NJ>;
+    const DecodeArgs &a = pack.part[blockIdx.y];
+    if ((int64_t)blockIdx.x >= a.n_streams) return;
+    const uint16_t *cdf = a.cdf;
+    const int Lp = a.Lp;
+    const int64_t table_bytes = a.table_bytes;
+    const uint32_t n_sym = a.n_sym;
+    const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
@@ -644,8 +684,12 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
     const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
     const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
-    int16_t *dst = sym_out + s * (int64_t)n_sym;
-    if (!FAST && !force && dst[0] != (int16_t)-1) return;   // decoded by the FAST pass
+    int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
+    if (FAST && !validated) {   // not a table for the fast path: leave the whole chunk to the generic pass
+        if (lane == 0) dst[0] = (int16_t)-1;
+        return;
+    }
+    if (!FAST && !a.force && validated && dst[0] != (int16_t)-1) return;   // decoded by the FAST pass
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
 
     auto request_block = [&](uint32_t k) {   // DMA the 16-byte granules holding rows [kR, (k+1)R) into slot k % NB
@@ -665,9 +709,19 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
     };
 
     WaveBits src;
-    src.init(reinterpret_cast<const uint32_t *>(in + in_offsets[s]), in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES);
-    uint32_t low = 0, high = 0xFFFFFFFFu;
-    uint32_t value = src.take(32);
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(a.in + a.in_offsets[s]);
+    uint32_t low = 0, high = 0xFFFFFFFFu, value;
+    if (a.state_in) {
+        const DecodeState st = a.state_in[s];
+        src.init(words, a.in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES, st.next, st.acc, st.nb);
+        low = st.low;
+        high = st.high;
+        value = st.value;
+    } else {
+        src.init(words, a.in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES);
+        value = src.take(32);
+    }
+    const uint32_t no_advance = a.final_chunk ? n_sym - 1u : 0xFFFFFFFFu;   // torchac.cpp:335-337
 
 #pragma unroll
     for (uint32_t k = 0; k < (uint32_t)C::NB - 1u; ++k)
@@ -704,9 +758,9 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
             uint32_t x = 0;
             bool ok = true;
             if (FAST)
-                ok = decode_symbol_fast<NJ>(row, valid, low, high, value, src, top, i != n_sym - 1u, x);
+                ok = decode_symbol_fast<NJ>(row, valid, low, high, value, src, top, i != no_advance, x);
             else
-                x = decode_symbol<NJ>(row, low, high, value, src, top, monotone != 0, i != n_sym - 1u);
+                x = decode_symbol<NJ>(row, low, high, value, src, top, validated, i != no_advance);
             keep_symbol(dst, i, n_sym, x, lane, kept);
             lds_row_take(row, pending);   // the only take of the loop, on every path (tools/check_asm_prefetch.py)
             if (FAST && __builtin_expect(!ok, 0)) {
@@ -716,6 +770,7 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const uint16_t *__re
             }
         }
     }
+    if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.next, src.acc, src.nb, 0u};
 }
 
 __global__ __launch_bounds__(256) void check_monotone_kernel(const uint16_t *__restrict__ cdf, int64_t n_rows, int Lp,
@@ -736,6 +791,24 @@ int grid_for(int64_t total, int block, int max_blocks = 256 * 8) {
     int64_t g = (total + block - 1) / block;
     if (g < 1) g = 1;
     return (int)(g > max_blocks ? max_blocks : g);
+}
+
+// All parts must be of one alphabet class (Lp <= 65 or larger: the kernel instantiation) and agree on `fast_pass`.
+int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStream_t st) {
+    int64_t max_streams = 0;
+    for (int i = 0; i < n_parts; ++i) max_streams = pack.part[i].n_streams > max_streams ? pack.part[i].n_streams : max_streams;
+    const dim3 grid((unsigned)max_streams, (unsigned)n_parts), block(64);
+    const bool small = pack.part[0].Lp - 1 <= 64;
+    if (fast_pass) {   // streams that leave the fast path (or all, if the table is not validated) mark themselves
+        if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1, true>), grid, block, 0, st, pack);
+        else hipLaunchKernelGGL((ac_decode_ring_kernel<4, true>), grid, block, 0, st, pack);
+        const int rc = l3c::check_launch("ac_decode_ring_kernel<fast>");
+        if (rc != L3C_OK) return rc;
+    }
+    for (int i = 0; i < n_parts; ++i) pack.part[i].force = fast_pass ? 0 : 1;
+    if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1, false>), grid, block, 0, st, pack);
+    else hipLaunchKernelGGL((ac_decode_ring_kernel<4, false>), grid, block, 0, st, pack);
+    return l3c::check_launch("ac_decode_ring_kernel<generic>");
 }
 
 }  // namespace
@@ -847,22 +920,59 @@ int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t
             hipLaunchKernelGGL(ac_decode_const_row_kernel<4>, grid, block, 0, st, cdf, Lp, in, in_offsets, in_nbytes, n, monotone, sym_out);
         return l3c::check_launch("ac_decode_const_row_kernel");
     }
-    const int64_t table_bytes = n_streams * n_sym * (int64_t)Lp * 2;
-    const bool small = Lp - 1 <= 64;
-    if (monotone) {   // fast pass; streams that leave the fast path mark themselves for the generic pass
-        if (small)
-            hipLaunchKernelGGL((ac_decode_ring_kernel<1, true>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, 1, 0, sym_out);
-        else
-            hipLaunchKernelGGL((ac_decode_ring_kernel<4, true>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, 1, 0, sym_out);
-        const int rc = l3c::check_launch("ac_decode_ring_kernel<fast>");
-        if (rc != L3C_OK) return rc;
+    DecodeArgs a{};
+    a.cdf = cdf;
+    a.Lp = Lp;
+    a.table_bytes = n_streams * n_sym * (int64_t)Lp * 2;
+    a.in = in;
+    a.in_offsets = in_offsets;
+    a.in_nbytes = in_nbytes;
+    a.n_sym = n;
+    a.monotone = monotone;
+    a.final_chunk = 1;
+    a.sym_out = sym_out;
+    a.sym_stride = n_sym;
+    a.n_streams = n_streams;
+    DecodeArgsPack pack{};
+    pack.part[0] = a;
+    return launch_ring_decode(pack, 1, /*fast_pass=*/monotone != 0, st);
+}
+
+int64_t l3c_ac_decode_state_bytes(void) { return (int64_t)sizeof(DecodeState); }
+
+int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_stream_t stream) {
+    L3C_REQUIRE(parts && n_parts > 0 && n_parts <= DecodeArgsPack::N, "1..8 parts per call");
+    DecodeArgsPack pack{};
+    for (int i = 0; i < n_parts; ++i) {
+        const l3c_ac_decode_part &q = parts[i];
+        L3C_REQUIRE(q.cdf && q.in && q.in_offsets && q.in_nbytes && q.sym_out, "null pointer in part");
+        L3C_REQUIRE(q.Lp >= 2 && q.Lp <= 257, "Lp out of range (2..257)");
+        L3C_REQUIRE((q.Lp - 1 <= 64) == (parts[0].Lp - 1 <= 64), "parts of one call must share the alphabet class (Lp <= 65 or not)");
+        L3C_REQUIRE((q.not_monotone_flag != nullptr) == (parts[0].not_monotone_flag != nullptr), "parts must agree on having a validity flag");
+        L3C_REQUIRE(q.n_streams > 0 && q.n_sym > 0 && q.n_sym < (1ll << 31), "bad shape");
+        L3C_REQUIRE(q.sym_offset >= 0 && q.sym_stride >= q.n_sym, "bad output layout");
+        L3C_REQUIRE((reinterpret_cast<uintptr_t>(q.in) & 3) == 0 && (reinterpret_cast<uintptr_t>(q.cdf) & 1) == 0, "misaligned input");
+        L3C_REQUIRE(((reinterpret_cast<uintptr_t>(q.state_in) | reinterpret_cast<uintptr_t>(q.state_out)) & 7) == 0, "misaligned state");
+        L3C_REQUIRE(q.state_in != q.state_out || !q.state_in, "state_in and state_out must differ (a marked stream is decoded twice)");
+        DecodeArgs &a = pack.part[i];
+        a.cdf = q.cdf;
+        a.Lp = q.Lp;
+        a.table_bytes = q.n_streams * q.n_sym * (int64_t)q.Lp * 2;
+        a.in = q.in;
+        a.in_offsets = q.in_offsets;
+        a.in_nbytes = q.in_nbytes;
+        a.n_streams = q.n_streams;
+        a.n_sym = (uint32_t)q.n_sym;
+        a.monotone = 0;
+        a.flag = q.not_monotone_flag;
+        a.final_chunk = q.final_chunk;
+        a.state_in = static_cast<const DecodeState *>(q.state_in);
+        a.state_out = static_cast<DecodeState *>(q.state_out);
+        a.sym_out = q.sym_out;
+        a.sym_stride = q.sym_stride;
+        a.sym_offset = q.sym_offset;
     }
-    const int force = monotone ? 0 : 1;
-    if (small)
-        hipLaunchKernelGGL((ac_decode_ring_kernel<1, false>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, force, sym_out);
-    else
-        hipLaunchKernelGGL((ac_decode_ring_kernel<4, false>), grid, block, 0, st, cdf, Lp, table_bytes, in, in_offsets, in_nbytes, n, monotone, force, sym_out);
-    return l3c::check_launch("ac_decode_ring_kernel<generic>");
+    return launch_ring_decode(pack, n_parts, /*fast_pass=*/parts[0].not_monotone_flag != nullptr, l3c::as_stream(stream));
 }
 
 int l3c_cdf_check_monotone(const uint16_t *cdf, int64_t n_rows, int Lp, int32_t *flag_out, l3c_stream_t stream) {

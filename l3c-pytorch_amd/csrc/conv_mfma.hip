@@ -263,9 +263,13 @@ __global__ __launch_bounds__(256, (MT >= 4 ? 2 : 3)) void conv_mfma_kernel(const
 // CK_ = input channels per chunk; WN = waves along N: the 8 waves are WM x WN, each wave MT=2 rows x 64 output channels, so a
 // block covers a (WM*2) x 32 tile and WN consecutive 64-channel output chunks.  3x3: CK 16, WN 1 (16 x 32 tile).
 // 1x1 (192 -> 120/150): CK 64, WN 2 (8 x 32 tile, both output chunks of Kp = 120 in one block: the patch is staged once).
-template <int KS, int DIL, int CK_ = 16, int WN_ = 1>
+// NW_ = waves per block (8, or 4: two blocks then share a CU and cover each other's barrier / DMA stalls), SLABS_ = weight slab
+// buffers (2 = the next chunk's slab is DMA'd during the MFMA loop; 1 = fetched between the two barriers, for the NW_ = 4
+// layout whose LDS budget is 80 KB per block).
+template <int KS, int DIL, int CK_ = 16, int WN_ = 1, int NW_ = 8, int SLABS_ = 2>
 struct Geo3 {
-    static constexpr int MT = 2, CK = CK_, GPC = CK_ / 8, WN = WN_, WM = 8 / WN_;
+    static constexpr int NW = NW_, SLABS = SLABS_, THREADS = NW_ * 64;
+    static constexpr int MT = 2, CK = CK_, GPC = CK_ / 8, WN = WN_, WM = NW_ / WN_;
     static constexpr int TH = WM * MT;
     static constexpr int IH = TH + (KS - 1) * DIL, IW = TW + (KS - 1) * DIL;
     static constexpr int PS = CK + 4;
@@ -273,12 +277,13 @@ struct Geo3 {
     static constexpr int A_FLOATS = IH * IW * PS;
     static constexpr int BW_FLOATS = TAPS * GPC * 2 * 256;          // one chunk's weight slab for ONE 64-channel output chunk
     static constexpr int B_FLOATS = WN * BW_FLOATS;
-    static constexpr int LDS_BYTES = (A_FLOATS + 2 * B_FLOATS) * 4;
+    static constexpr int LDS_BYTES = (A_FLOATS + SLABS * B_FLOATS) * 4;
 };
 
-template <int KS, int DIL, int CK_, int WN_>
-__global__ __launch_bounds__(512, (CK_ <= 8 ? 4 : 2)) void conv_lds_kernel(const ConvParams p) {
-    using G = Geo3<KS, DIL, CK_, WN_>;
+template <int KS, int DIL, int CK_, int WN_, int NW_, int SLABS_>
+__global__ __launch_bounds__(NW_ * 64, 2) void conv_lds_kernel(const ConvParams p) {
+    using G = Geo3<KS, DIL, CK_, WN_, NW_, SLABS_>;
+    constexpr int NT_ = G::THREADS;
     constexpr int MT = G::MT, CK = G::CK, GPC = G::GPC, NSTEPS = G::TAPS * GPC;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *lds_a = lds;
@@ -304,14 +309,14 @@ __global__ __launch_bounds__(512, (CK_ <= 8 ? 4 : 2)) void conv_lds_kernel(const
     const int n_groups_o = (p.n_chunks_o + G::WN - 1) / G::WN;
     constexpr int V = CK / 4;
     constexpr int TOTAL = G::IH * G::IW * V;
-    constexpr int NIT = (TOTAL + 511) / 512;
+    constexpr int NIT = (TOTAL + NT_ - 1) / NT_;
     f32x4 stage_regs[NIT];
-    // fetch stage s: weight slab -> LDS slab (s & 1) by DMA, input patch -> registers
-    auto fetch = [&](int s_) {
+    // stage s: weight slab -> LDS slab (s % SLABS) by DMA ...
+    auto fetch_slab = [&](int s_) {
         const int item = first + s_ / n_cc, cc = s_ % n_cc;
-        const int tile = item % tiles, group_o = (item / tiles) % n_groups_o, b = item / tiles / n_groups_o;
-        float *dst = lds_b + (s_ & 1) * G::B_FLOATS;
-        for (int j = wave; j < NB_DMA; j += 8) {
+        const int group_o = (item / tiles) % n_groups_o;
+        float *dst = lds_b + (s_ % G::SLABS) * G::B_FLOATS;
+        for (int j = wave; j < NB_DMA; j += G::NW) {
             // slab part of output chunk group_o*WN + j / NBW (clamped: a partial last group re-reads the last chunk)
             int co = group_o * G::WN + j / NBW;
             co = co < p.n_chunks_o ? co : p.n_chunks_o - 1;
@@ -319,11 +324,16 @@ __global__ __launch_bounds__(512, (CK_ <= 8 ? 4 : 2)) void conv_lds_kernel(const
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                              (__attribute__((address_space(3))) void *)(dst + j * 256), 16, 0, 0);
         }
+    };
+    // ... and its input patch -> registers
+    auto fetch_patch = [&](int s_) {
+        const int item = first + s_ / n_cc, cc = s_ % n_cc;
+        const int tile = item % tiles, b = item / tiles / n_groups_o;
         const int iy0 = (tile / p.tiles_x) * G::TH - p.pad, ix0 = (tile % p.tiles_x) * TW - p.pad;
         const float *in_b = p.in + (size_t)b * p.Hin * p.Win * p.in_cstride + p.in_coff + cc * CK;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 512;
+            const int i = tid + it * NT_;
             const int c4 = i % V, pix = i / V;
             const int r = pix / G::IW, ci = pix % G::IW;
             const int iy = iy0 + r, ix = ix0 + ci;
@@ -336,13 +346,16 @@ __global__ __launch_bounds__(512, (CK_ <= 8 ? 4 : 2)) void conv_lds_kernel(const
     auto store_patch = [&]() {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 512;
+            const int i = tid + it * NT_;
             const int c4 = i % V, pix = i / V;
             if (i < TOTAL) *reinterpret_cast<f32x4 *>(&lds_a[pix * G::PS + c4 * 4]) = stage_regs[it];
         }
     };
 
-    if (n_stages > 0) fetch(0);
+    if (n_stages > 0) {
+        if (G::SLABS == 2) fetch_slab(0);
+        fetch_patch(0);
+    }
     const float *a_lane = lds_a + ((wm * MT) * G::IW + lx) * G::PS + half * 4;
     int stage = 0;
     for (int it_ = 0; it_ < count; ++it_) {
@@ -357,11 +370,15 @@ __global__ __launch_bounds__(512, (CK_ <= 8 ? 4 : 2)) void conv_lds_kernel(const
 
         for (int cc = 0; cc < n_cc; ++cc, ++stage) {
             if (stage) __syncthreads();                        // everyone is done reading the patch and slab (stage+1)&1
+            if (G::SLABS == 1) fetch_slab(stage);              // single slab: only now free (the co-resident block computes meanwhile)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's patch registers and slab DMA have landed
             store_patch();
             __syncthreads();                                   // patch + slab of this stage visible to the whole block
-            if (stage + 1 < n_stages) fetch(stage + 1);
-            const float *b_lane = lds_b + (stage & 1) * G::B_FLOATS + wn * G::BW_FLOATS + lane * 4;
+            if (stage + 1 < n_stages) {
+                if (G::SLABS == 2) fetch_slab(stage + 1);
+                fetch_patch(stage + 1);
+            }
+            const float *b_lane = lds_b + (stage % G::SLABS) * G::B_FLOATS + wn * G::BW_FLOATS + lane * 4;
             f32x4 aq[2][MT], bq[2][2];
             auto load_ab = [&](int st, f32x4 (&a)[MT], f32x4 (&bb)[2]) {
                 const int tap = st / GPC, g = st % GPC;
@@ -561,9 +578,9 @@ int num_cus() {
     return n;
 }
 
-template <int KS, int DIL, int CK_ = 16, int WN_ = 1>
+template <int KS, int DIL, int CK_ = 16, int WN_ = 1, int NW_ = 8, int SLABS_ = 2>
 int launch_lds(ConvParams &p, hipStream_t stream) {
-    using G = Geo3<KS, DIL, CK_, WN_>;
+    using G = Geo3<KS, DIL, CK_, WN_, NW_, SLABS_>;
     static_assert(G::LDS_BYTES <= 160 * 1024, "LDS budget exceeded");
     L3C_REQUIRE(p.Cin % G::CK == 0, "Cin must be a multiple of the channel chunk");
     p.tiles_x = (p.Wout + TW - 1) / TW;
@@ -574,7 +591,7 @@ int launch_lds(ConvParams &p, hipStream_t stream) {
     p.total_blocks = (int)total;
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in
     if (!attr_set) {
-        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lds_kernel<KS, DIL, CK_, WN_>),
+        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lds_kernel<KS, DIL, CK_, WN_, NW_, SLABS_>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES),
                                       "hipFuncSetAttribute");
         if (rc != L3C_OK) return rc;
@@ -587,7 +604,7 @@ int launch_lds(ConvParams &p, hipStream_t stream) {
     static const int items_per_block = getenv("L3C_CONV_ITEMS_PER_BLOCK") ? atoi(getenv("L3C_CONV_ITEMS_PER_BLOCK")) : 1;
     const int ipb = items_per_block > 0 ? items_per_block : 1;
     const unsigned grid = (unsigned)((total + ipb - 1) / ipb);
-    hipLaunchKernelGGL((conv_lds_kernel<KS, DIL, CK_, WN_>), dim3(grid), dim3(512), G::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_lds_kernel<KS, DIL, CK_, WN_, NW_, SLABS_>), dim3(grid), dim3(G::THREADS), G::LDS_BYTES, stream, p);
     return l3c::check_launch("conv_lds_kernel");
 }
 
@@ -620,7 +637,6 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
         const int dbg = (d->epilogue >> 8) & 3;
         return dbg == 1 ? launch<3, 1, 1, 16, 2, 1>(p, s) : dbg == 2 ? launch<3, 1, 1, 16, 2, 2>(p, s) : launch<3, 1, 1, 16, 2, 3>(p, s);
     }
-    if (d->KS == 3 && d->dilation == 1 && (d->epilogue & 4096)) return launch_lds<3, 1, 8, 1>(p, s);   // probe: 2 blocks per CU
     if (d->KS == 3 && d->dilation == 1) return (d->epilogue & 2048) ? launch<3, 1, 1, 16, 2>(p, s) : launch_lds<3, 1>(p, s);
     if (d->KS == 3 && d->dilation == 2) return (d->epilogue & 2048) ? launch<3, 1, 2, 16, 2>(p, s) : launch_lds<3, 2>(p, s);
     if (d->KS == 3 && d->dilation == 4) return (d->epilogue & 2048) ? launch<3, 1, 4, 16, 2>(p, s) : launch_lds<3, 4>(p, s);

@@ -148,6 +148,81 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const float *__restrict_
     }
 }
 
+// ---- decoder, fused: P (+ the channels decoded so far) -> uint16 table rows of ONE channel over a pixel range -----------
+// channel_params_kernel + cdf_table_kernel in one pass, without the (B,K,H,W) x 3 parameter arrays in between, for the
+// chunk-pipelined RGB decode (R, G and B of an image are decoded a chunk apart, each chunk's table built just in time from
+// the symbols the previous channel has produced).  Same device functions, same operation order as the two-kernel path and
+// as encode_intervals_kernel: identical entries.
+__global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
+                                                               const float *__restrict__ targets, int64_t HW, int C, int K,
+                                                               int rgb, int c, int64_t range0, int64_t range_len, int Lp,
+                                                               uint16_t *__restrict__ cdf) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [kTablePix][Kp + 1]
+    __shared__ float s_pi[kTablePix][kMaxK], s_mu[kTablePix][kMaxK], s_inv[kTablePix][kMaxK];
+    __shared__ float s_max[kTablePix], s_den[kTablePix];
+    __shared__ float s_t[260];
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const int ld = Kp + 1;
+    const int64_t b = blockIdx.y;
+    const int64_t off = (int64_t)blockIdx.x * kTablePix;          // offset inside the range
+    const int64_t pix0 = range0 + off;
+    const int npix = (int)((range_len - off) < kTablePix ? (range_len - off) : kTablePix);
+    const int tid = threadIdx.x;
+    const float *src = P + (b * HW + pix0) * Kp;
+    for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+    for (int i = tid; i < Lp; i += 256) s_t[i] = targets[i];
+    __syncthreads();
+    if (tid < npix) {
+        const float *px = tile + tid * ld;
+        const MixStats st = mix_stats([&](int ch) { return px[ch]; }, C, K, c);
+        s_max[tid] = st.max_logit;
+        s_den[tid] = st.denom;
+    }
+    __syncthreads();
+    for (int i = tid; i < kTablePix * K; i += 256) {
+        const int p = i % kTablePix, k = i / kTablePix;
+        if (p < npix) {
+            const float *px = tile + p * ld;
+            const int64_t n = pix0 + p;
+            float x0 = 0.f, x1 = 0.f;
+            if (rgb && c > 0) {
+                x0 = (float)sym[(b * C + 0) * HW + n];
+                if (c > 1) x1 = (float)sym[(b * C + 1) * HW + n];
+            }
+            MixStats st;
+            st.max_logit = s_max[p];
+            st.denom = s_den[p];
+            const MixComponent m = mix_component([&](int ch) { return px[ch]; }, st, C, K, rgb, c, k, x0, x1);
+            s_pi[p][k] = m.pi;
+            s_mu[p][k] = m.mu;
+            s_inv[p][k] = expf(-m.log_sigma);
+        }
+    }
+    __syncthreads();
+    const float scale = (float)(65536 - (Lp - 1));
+    const int count = npix * Lp;
+    uint16_t *out = cdf + (b * range_len + off) * Lp;
+    const bool aligned4 = ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+    for (int e = tid * 2; e < count; e += 512) {
+        uint32_t v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ee = e + h < count ? e + h : e;
+            const int p = ee / Lp, l = ee - p * Lp;
+            const float t = s_t[l];
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = acc + cdf_term(s_pi[p][k], s_mu[p][k], s_inv[p][k], t);
+            v[h] = cdf_quantise(acc, scale, l);
+        }
+        if (aligned4 && e + 1 < count) {
+            *reinterpret_cast<uint32_t *>(out + e) = v[0] | (v[1] << 16);
+        } else {
+            out[e] = (uint16_t)v[0];
+            if (e + 1 < count) out[e + 1] = (uint16_t)v[1];
+        }
+    }
+}
+
 // ---- fused encoder head: P + symbols -> packed coding intervals -------------------------------------------------------
 
 constexpr int kHeadPix = 64;  // == interval block length, so one block writes whole 256-byte interval runs
@@ -343,6 +418,26 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
                        Lp, cdf);
     int rc = l3c::check_launch("cdf_table_kernel");
     if (rc == L3C_OK && not_monotone) rc = l3c_cdf_check_monotone(cdf, n_img * HW, Lp, not_monotone, stream);
+    return rc;
+}
+
+int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
+                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, l3c_stream_t stream) {
+    L3C_REQUIRE(P && targets && cdf, "null pointer");
+    L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && c >= 0 && c < C, "bad shape");
+    L3C_REQUIRE(pix0 >= 0 && npix > 0 && pix0 + npix <= HW, "pixel range outside the image");
+    L3C_REQUIRE(K > 0 && K <= kMaxK, "K out of range (1..16)");
+    L3C_REQUIRE(Lp >= 2 && Lp <= 260, "Lp out of range (2..260)");
+    L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
+    L3C_REQUIRE(!(rgb && c > 0) || sym, "the RGB scale needs the symbols of the channels decoded so far");
+    const int Kp = (rgb ? 4 : 3) * C * K;
+    const size_t lds = (size_t)kTablePix * (Kp + 1) * sizeof(float);
+    L3C_REQUIRE(lds <= 48 * 1024, "Kp too large for the LDS tile");
+    const dim3 grid((unsigned)((npix + kTablePix - 1) / kTablePix), (unsigned)B);
+    hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, c,
+                       pix0, npix, Lp, cdf);
+    int rc = l3c::check_launch("cdf_table_from_P_kernel");
+    if (rc == L3C_OK && not_monotone) rc = l3c_cdf_check_monotone(cdf, B * npix, Lp, not_monotone, stream);
     return rc;
 }
 

@@ -192,6 +192,18 @@ def cdf_table_mixture(targets, pi, mu, log_sigma, check_monotone=True):
     return cdf, flag
 
 
+def dmll_cdf_table(P_nhwc, sym, targets, C, K, rgb, c, pix0, npix, flag=None):
+    """Fused decoder head: uint16 table rows (viewed as int16, (B, npix, Lp)) of channel c for pixels [pix0, pix0 + npix) of
+    every image; `flag` (int32[1], device) is set if a row is not strictly increasing (never cleared)."""
+    B, H, W, _ = P_nhwc.shape
+    Lp = targets.shape[0]
+    cdf = torch.empty(B, npix, Lp, dtype=torch.int16, device=P_nhwc.device)
+    call('l3c_dmll_cdf_table', ptr(P_nhwc, torch.float32), ptr(sym, torch.int16) if sym is not None else None,
+         ptr(targets, torch.float32), B, H * W, C, K, int(rgb), c, pix0, npix, Lp, ptr(cdf),
+         ptr(flag, torch.int32) if flag is not None else None, stream())
+    return cdf
+
+
 def dmll_encode_intervals(P_nhwc, sym, targets, C, K, rgb):
     """P (B,H,W,Kp), sym int16 (B,C,H,W) -> packed interval words for the B*C streams of this scale."""
     B, H, W, _ = P_nhwc.shape
@@ -285,6 +297,32 @@ def ac_decode(cdf, payload_buf, offsets, nbytes, n_streams, n_sym, monotone, bro
     call('l3c_ac_decode', ptr(cdf), 0 if broadcast_row else Lp, Lp, ptr(payload_buf, torch.uint8),
          ptr(offsets, torch.int64), ptr(nbytes, torch.int32), n_streams, n_sym, int(bool(monotone)), ptr(sym), stream())
     return sym
+
+
+def ac_decode_state(n_streams, device='cuda'):
+    """Opaque per-stream coder state carried between the chunks of l3c_ac_decode_chunk."""
+    return torch.empty(n_streams * _lib.load().l3c_ac_decode_state_bytes(), dtype=torch.uint8, device=device)
+
+
+def ac_decode_part(cdf, payload_buf, offsets, nbytes, n_streams, n_sym, flag, state_in, state_out, final, sym_out,
+                   sym_stride, sym_offset):
+    """One part of `ac_decode_chunks`: decode symbols [sym_offset, sym_offset + n_sym) of every stream from the table rows of
+    that range (cdf: (n_streams * n_sym, Lp)), resuming from `state_in` (None: start of the streams) and saving into
+    `state_out`; writes into `sym_out` (int16, row stride `sym_stride`).  `flag`: device int32 'table not validated'
+    (None: treat as not validated).  The tuple keeps the tensors alive until the launch."""
+    part = _lib.AcDecodePart(ptr(cdf), cdf.shape[-1], ptr(payload_buf, torch.uint8), ptr(offsets, torch.int64),
+                             ptr(nbytes, torch.int32), n_streams, n_sym,
+                             ptr(flag, torch.int32) if flag is not None else None,
+                             ptr(state_in) if state_in is not None else None,
+                             ptr(state_out) if state_out is not None else None, int(bool(final)),
+                             ptr(sym_out, torch.int16), sym_stride, sym_offset)
+    return part, (cdf, payload_buf, offsets, nbytes, flag, state_in, state_out, sym_out)
+
+
+def ac_decode_chunks(parts):
+    """1..8 independent parts (see ac_decode_part) decoded side by side in one launch pair."""
+    arr = (_lib.AcDecodePart * len(parts))(*[p for p, _ in parts])
+    call('l3c_ac_decode_chunks', arr, len(parts), stream())
 
 
 def table_is_monotone(cdf):

@@ -117,6 +117,35 @@ def test_foreign_streams_decode_like_the_reference(Lp, N):
             assert (dec[s] == want[s]).all(), (monotone, s, int((dec[s] != want[s]).sum()))
 
 
+@pytest.mark.parametrize('Lp,N,cuts', [(257, 1000, (0, 64, 576, 1000)), (26, 5000, (0, 2048, 2112, 4992, 5000)), (257, 130, (0, 130))])
+def test_chunked_decode_resumes_exactly(Lp, N, cuts):
+    """l3c_ac_decode_chunks: a stream decoded in pieces (state carried through the opaque per-stream record, table rows of
+    each piece in their own buffer, validity as a DEVICE flag) gives the symbols of the one-shot decode; a foreign stream in
+    the batch takes the generic pass chunk by chunk; a set flag sends everything through the generic pass."""
+    from l3c_pytorch_amd import ops
+    from tests import gpu_util as gu
+    rng = np.random.RandomState(N)
+    S = 5
+    tabs = gu.random_tables(rng, S, N, Lp, shape=0.3)
+    syms = gu.sample_symbols(rng, tabs)
+    payloads = [oracle_ac.encode(tabs[s], syms[s]) for s in range(S)]
+    payloads[2] = rng.randint(0, 256, size=len(payloads[2]), dtype=np.uint8).tobytes()
+    want = np.stack([oracle_ac.decode(tabs[s], payloads[s], N) for s in range(S)])
+    buf, offs, lens = ops.pack_streams(payloads)
+    for flag_value in (0, 1):
+        out = torch.full((S, N + 7), -7, dtype=torch.int16, device='cuda')      # row stride != chunk length
+        flag = torch.full((1,), flag_value, dtype=torch.int32, device='cuda')
+        states = [ops.ac_decode_state(S), ops.ac_decode_state(S)]
+        for j in range(len(cuts) - 1):
+            p0, n = cuts[j], cuts[j + 1] - cuts[j]
+            chunk = torch.from_numpy(np.ascontiguousarray(tabs[:, p0:p0 + n]).view(np.int16)).cuda().reshape(S * n, Lp)
+            ops.ac_decode_chunks([ops.ac_decode_part(chunk, buf, offs, lens, S, n, flag, states[(j + 1) & 1] if j else None,
+                                                     states[j & 1], j == len(cuts) - 2, out, N + 7, p0)])
+        got = out.cpu().numpy()
+        assert (got[:, :N] == want).all(), (flag_value, [int((got[s, :N] != want[s]).sum()) for s in range(S)])
+        assert (got[:, N:] == -7).all()
+
+
 def test_uniform_row_broadcast():
     from l3c_pytorch_amd import ops
     from l3c_pytorch_amd.bitcoding.bitcoding import uniform_cdf_row

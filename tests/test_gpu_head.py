@@ -148,3 +148,24 @@ def test_sample_kernel_vs_oracle(rgb, C, H, W):
     assert bad < 1e-3, bad
     if rgb:
         assert got.min() >= 0 and got.max() <= 255
+
+
+@pytest.mark.parametrize('rgb,C,c', [(True, 3, 0), (True, 3, 2), (False, 5, 3)])
+def test_fused_table_rows_equal_the_two_kernel_table(rgb, C, c):
+    """l3c_dmll_cdf_table (P -> rows of a pixel range, fused) == l3c_dmll_channel_params + l3c_cdf_table_mixture on the same
+    pixels, bit for bit -- the chunk-pipelined RGB decoder and the encoder's fused intervals read the same numbers."""
+    from l3c_pytorch_amd import ops
+    rng = np.random.RandomState(c)
+    B, K, H, W = 2, 10, 12, 20
+    spec = odmll.RGB if rgb else odmll.z_spec()
+    P = torch.from_numpy(_rand_P(rng, B, H, W, C, K, rgb)).cuda()
+    sym = torch.from_numpy(rng.randint(0, spec.L, size=(B, C, H, W)).astype(np.int16)).cuda()
+    targets = ocdf.coding_targets(spec.x_min, spec.x_max, spec.L).cuda()
+    pi, mu, ls = ops.dmll_channel_params(P, sym if rgb else None, C, K, rgb, c)
+    full, flag = ops.cdf_table_mixture(targets, pi, mu, ls)
+    full = full.reshape(B, H * W, -1)
+    for p0, n in [(0, H * W), (32, 64), (7, 50), (H * W - 33, 33)]:
+        f = torch.zeros(1, dtype=torch.int32, device='cuda')
+        part = ops.dmll_cdf_table(P, sym if rgb else None, targets, C, K, rgb, c, p0, n, f)
+        assert torch.equal(part[..., :-1], full[:, p0:p0 + n, :-1]), (p0, n)
+        assert int(f.item()) == int(flag.item())
