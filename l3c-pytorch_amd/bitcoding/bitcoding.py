@@ -287,7 +287,7 @@ class Bitcoding(object):
             ops.ac_decode_chunks(parts[k:k + 8])
         return sym
 
-    RGB_CHUNKS = 8
+    RGB_CHUNKS = 16
 
     def _decode_rgb_pipelined(self, P, targets, payloads, B, C, K, H, W):
         """The RGB scale: channel c's means depend on the decoded values of the channels < c AT THE SAME PIXEL
