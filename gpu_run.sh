@@ -1,5 +1,2 @@
-for N in 8 16 32; do
-echo chunks=$N
-L3C_RGB_CHUNKS=$N timeout 300 python tools/codec_probe.py --B 8 2>&1 | tail -1
-L3C_RGB_CHUNKS=$N timeout 300 python tools/codec_probe.py --B 64 2>&1 | tail -1
-done
+timeout 900 python -m pytest tests/test_gpu_net.py -m gpu -q -x --timeout 300 -k "auto_crop or cli or driver" 2>&1 | tail -5
+timeout 900 python gpurun_dbg.py 2>&1 | grep -v "INFO\|Need to\|Stitching" | tail -4

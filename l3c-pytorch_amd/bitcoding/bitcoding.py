@@ -332,11 +332,7 @@ class Bitcoding(object):
 
         if auto_crop.needs_crop(img):
             print('Need to encode individual crops!')
-            comb = auto_crop.CropLossCombinator()
-            for i, crop in enumerate(auto_crop.iter_crops(img)):
-                bpsp_crop = self.encode(crop, pout + part_suffix_helper.make_part_suffix(i))
-                comb.add(bpsp_crop, int(np.prod(crop.shape[-2:])))
-            return comb.get_bpsp()
+            return self._encode_crops(list(auto_crop.iter_crops(img)), pout)
 
         fac = 2 ** self.blueprint.net.config_ms.num_scales
         _, _, H, W = img.shape
@@ -365,10 +361,57 @@ class Bitcoding(object):
                   '[{} bytes]'.format(tostr(theory), tostr(list(reversed(per_scale))), overhead, actual_bpsp, len(data)))
         return actual_bpsp
 
+    def _encode_crops(self, crops, pout):
+        """The auto-crops of a large image (reference :63-71 codes them one after the other): crops of equal padded shape
+        share a batch, all batches share ONE grouped coder launch (encode_many); part i goes to `pout`.part<i> as before."""
+        fac = 2 ** self.blueprint.net.config_ms.num_scales
+        padded, pads, groups = [], [], {}
+        for i, crop in enumerate(crops):
+            assert not os.path.isfile(pout + part_suffix_helper.make_part_suffix(i))
+            _, _, H, W = crop.shape
+            if H % fac != 0 or W % fac != 0:
+                print('*** INFO: image shape ({}X{}) not divisible by {}, will pad.'.format(H, W, fac))
+                crop, pt = pad.pad(crop, fac=fac, mode=self.blueprint.get_padding_mode())
+            else:
+                pt = (0, 0, 0, 0)
+            padded.append(crop)
+            pads.append(pt)
+            groups.setdefault(tuple(crop.shape[-2:]), []).append(i)
+        order = list(groups.values())
+        with self.times.run('[-] encode forwardpass + coder, {} crops'.format(len(crops))):
+            encs = self.encode_many([torch.cat([padded[i] for i in idxs]).to('cuda', torch.float32) for idxs in order])
+        comb = auto_crop.CropLossCombinator()
+        sizes = {}
+        for idxs, enc in zip(order, encs):
+            for i, data in zip(idxs, enc.to_bytes([pads[i] for i in idxs])):
+                with open(pout + part_suffix_helper.make_part_suffix(i), 'wb') as fout:
+                    fout.write(data)
+                sizes[i] = len(data)
+        for i, crop in enumerate(crops):     # as the reference: bpsp of a part over its PADDED sub-pixels, weighted by its area
+            comb.add(sizes[i] * 8 / int(np.prod(padded[i].shape)), int(np.prod(crop.shape[-2:])))
+        return comb.get_bpsp()
+
+    def _decode_parts(self, paths):
+        """Part files of one image: parts of equal (padded) shape are decoded as one batch."""
+        datas = []
+        for p in paths:
+            with open(p, 'rb') as fin:
+                datas.append(fin.read())
+        groups = {}
+        for i, d in enumerate(datas):
+            groups.setdefault(d[8:13], []).append(i)      # the coarsest scale's header (C, H, W) identifies the padded shape
+        parts = [None] * len(datas)
+        for idxs in groups.values():
+            out, padding = self.decode_batch([datas[i] for i in idxs])
+            for k, i in enumerate(idxs):
+                o = out[k:k + 1]
+                parts[i] = pad.undo_pad(o, *padding[k]) if any(padding[k]) else o
+        return parts
+
     def decode(self, pin, _recurse_part=True):
         """-> decoded image, 1CHW long (on the GPU)."""
         if _recurse_part and part_suffix_helper.contains_part_suffix(pin):
-            parts = [self.decode(p, _recurse_part=False) for p in part_suffix_helper.iter_part_suffixes(pin)]
+            parts = self._decode_parts(list(part_suffix_helper.iter_part_suffixes(pin)))
             print('Stitching {} parts...'.format(len(parts)))
             return auto_crop.stitch(parts)
         with open(pin, 'rb') as fin:

@@ -174,6 +174,21 @@ def test_auto_crop_parts(blueprint, tmp_path, monkeypatch):
     assert parts == ['big.l3c.part0', 'big.l3c.part1', 'big.l3c.part2', 'big.l3c.part3']
     back = bc.decode(p + '.part2')
     assert torch.equal(back.cpu(), img) and bpsp > 0
+    # crops that need padding (35x45 -> 40x48), 16 parts (recursive split): every part file equals the crop coded on its own
+    monkeypatch.setattr(auto_crop, '_NEEDS_CROP_DIM', 40 * 50)
+    img2 = synthetic.make_image(140, 180, 9, 'natural').unsqueeze(0).long()
+    p2 = str(tmp_path / 'odd.l3c')
+    bpsp2 = bc.encode(img2, p2)
+    crops = list(auto_crop.iter_crops(img2))
+    assert len(crops) == 16 and tuple(crops[0].shape[-2:]) == (35, 45)
+    comb = auto_crop.CropLossCombinator()
+    monkeypatch.setattr(auto_crop, '_NEEDS_CROP_DIM', 10 ** 9)
+    for i, crop in enumerate(crops):
+        single = str(tmp_path / 'single{}.l3c'.format(i))
+        comb.add(bc.encode(crop.clone(), single), 35 * 45)
+        assert open(single, 'rb').read() == open(p2 + '.part{}'.format(i), 'rb').read(), i
+    assert abs(comb.get_bpsp() - bpsp2) < 1e-12
+    assert torch.equal(bc.decode(p2 + '.part0').cpu(), img2)
 
 
 def test_l3c_cli_enc_dec_roundtrip(synthetic_l3c, tmp_path):
