@@ -389,7 +389,10 @@ __device__ __forceinline__ void vm_wait() {
 // picked up from there 64 words later.  No VGPR is the target of a load in the decode loop, so the compiler has nothing to
 // put an s_waitcnt vmcnt on (every such wait would also drain the table DMAs of the ring decoder).  `age` counts table blocks
 // started since the request: after 3 blocks the in-order vmcnt waits of the ring decoder have covered it, otherwise (short
-// streams, the constant-row kernel) the switch waits for everything.  take() is branch-free except for the window switch.
+// streams, the constant-row kernel) the switch waits for everything.
+// The reader is a bit POSITION plus the two stream words around it in an SGPR pair: the next 32 bits are one 64-bit shift
+// away (peek32), consuming c <= 32 bits into `value` is one more (shift_in), and a word is pulled out of the window VGPR
+// only when the position crosses a word boundary (every ~6 symbols) -- no per-symbol refill logic.
 struct WaveBits {
     const uint32_t *words;   // 4-byte aligned start of the stream
     uint32_t nbytes;
@@ -398,13 +401,12 @@ struct WaveBits {
     uint32_t base;           // first word index of `cur`
     uint32_t cur;            // per-lane window register
     uint32_t age;
-    uint64_t acc;            // low `nb` bits are unread stream bits
-    int nb;
-    uint32_t next;           // next word index to pull into acc
+    uint32_t pos;            // bit position of the next unread bit
+    uint64_t w01;            // stream words (pos >> 5) : (pos >> 5) + 1, zeros past the end
 
     __device__ __forceinline__ void request(uint32_t b) {   // window starting at word b -> buffer (b / 64) & 1
         const uint32_t idx = b + (uint32_t)lane;
-        if (idx * 4u < nbytes)    // lanes past the end leave stale LDS behind; finalise() zeroes them
+        if (idx * 4u < nbytes)    // lanes past the end leave stale LDS behind; pick_up() zeroes them
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(words + idx),
                                              (__attribute__((address_space(3))) void *)(uintptr_t)(lds + ((b >> 6) & 1u) * 256u),
                                              4, 0, 0);
@@ -424,37 +426,50 @@ struct WaveBits {
         }
         return w;
     }
-    // next0 / acc0 / nb0: where a previous chunk of the same stream stopped (0, 0, 0 = start of the stream)
-    __device__ __forceinline__ void init(const uint32_t *w, uint32_t n, int lane_, uint32_t lds_addr, uint32_t next0 = 0,
-                                         uint64_t acc0 = 0, int nb0 = 0) {
-        words = w;
-        nbytes = n;
-        lane = lane_;
-        lds = lds_addr;
-        base = next0 & ~63u;
-        request(base);
-        request(base + 64u);
-        vm_wait<0>();
-        cur = pick_up(base);
-        age = 3;
-        acc = acc0;
-        nb = nb0;
-        next = next0;
-    }
-    __device__ __forceinline__ uint32_t take(int count) {   // next `count` (0..32) bits, MSB first; zeros past the end
-        const uint32_t w = lane_read(cur, next - base);
-        const bool need = nb < count;
-        acc = need ? ((acc << 32) | w) : acc;
-        nb += need ? 32 : 0;
-        next += need ? 1u : 0u;
-        if (__builtin_expect(next - base >= 64u, 0)) {   // window exhausted (wave-uniform, once per 64 words)
+    // word `idx` of the stream; idx never decreases and grows by at most one window between calls
+    __device__ __forceinline__ uint32_t word(uint32_t idx) {
+        if (__builtin_expect(idx - base >= 64u, 0)) {   // window exhausted (wave-uniform, once per 64 words)
             base += 64u;
             if (age < 3u) vm_wait<0>();
             cur = pick_up(base);
             request(base + 64u);
         }
-        nb -= count;
-        return (uint32_t)(acc >> nb) & l3c::ones(count);
+        return lane_read(cur, idx - base);
+    }
+    // pos0: where a previous chunk of the same stream stopped (0 = start of the stream)
+    __device__ __forceinline__ void init(const uint32_t *w, uint32_t n, int lane_, uint32_t lds_addr, uint32_t pos0 = 0) {
+        words = w;
+        nbytes = n;
+        lane = lane_;
+        lds = lds_addr;
+        pos = pos0;
+        const uint32_t widx = pos0 >> 5;
+        base = widx & ~63u;
+        request(base);
+        request(base + 64u);
+        vm_wait<0>();
+        cur = pick_up(base);
+        age = 3;
+        const uint32_t w0 = word(widx);
+        w01 = ((uint64_t)w0 << 32) | word(widx + 1u);
+    }
+    __device__ __forceinline__ uint32_t peek32() const {   // the next 32 bits, MSB first
+        return (uint32_t)((w01 << (pos & 31u)) >> 32);
+    }
+    __device__ __forceinline__ void skip(int count) {       // count in 0..32
+        const uint32_t before = pos >> 5;
+        pos += (uint32_t)count;
+        const uint32_t after = pos >> 5;
+        if (after != before) w01 = (w01 << 32) | word(after + 1u);
+    }
+    // (value << count) | next `count` bits, count in 0..32
+    __device__ __forceinline__ uint32_t shift_in(uint32_t value, int count) {
+        const uint32_t r = (uint32_t)(((((uint64_t)value) << 32) | peek32()) << count >> 32);
+        skip(count);
+        return r;
+    }
+    __device__ __forceinline__ uint32_t take(int count) {   // next `count` (0..32) bits, MSB first; zeros past the end
+        return shift_in(0u, count);
     }
 };
 
@@ -507,24 +522,53 @@ __device__ __forceinline__ uint32_t decode_symbol(const Regs<NJ> &row, uint32_t 
 }
 
 // The fast path alone, for the FAST instantiation of the ring decoder (nothing but this in its loop).  Precondition:
-// validated (strictly increasing) table; `row` is NOT masked, `valid` marks the lanes that hold table entries.  A
-// renormalised interval of a validated table never collapses to one value (its width is >= 2^14), so the n == 32 case of
-// renorm_counts cannot occur.  Returns false -- state untouched -- when value is outside [low, high], which a stream of this
-// coder / the reference never produces; the stream is then decoded again by the generic instantiation.
+// validated (strictly increasing) table; `row16` holds the table entries SHIFTED LEFT BY 16 (lds_row_take_shifted), not
+// masked; `valid` marks the lanes that hold table entries.  With c16 = cdf << 16 the scaled entry (span * cdf) >> 16 is
+// the high half of c16 * span -- one v_mul_hi_u32 -- except for the full 32-bit range (span = 2^32), where it is c16
+// itself.  A renormalised interval of a validated table never collapses to one value (its width is >= 2^14), so the n == 32
+// case of renorm_counts cannot occur.  Returns false -- state untouched -- when value is outside [low, high], which a
+// stream of this coder / the reference never produces; the stream is then decoded again by the generic instantiation.
+__device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+__device__ __forceinline__ Regs<1> regs_mul_hi(const Regs<1> &r, uint32_t s) { return Regs<1>{mul_hi(r.a, s)}; }
+__device__ __forceinline__ Regs<4> regs_mul_hi(const Regs<4> &r, uint32_t s) {
+    return Regs<4>{mul_hi(r.a, s), mul_hi(r.b, s), mul_hi(r.c, s), mul_hi(r.d, s)};
+}
+// entries x and x1 = x + 1 of a row: pick the register holding x once (wave-uniform selects), two v_readlanes; only when x is
+// the last lane of a register does x1 live in the next one
+__device__ __forceinline__ void regs_fetch2(const Regs<1> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
+    lo = lane_read(r.a, x & 63u);
+    hi = lane_read(r.a, x1 & 63u);
+}
+__device__ __forceinline__ void regs_fetch2(const Regs<4> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
+    const uint32_t j = x >> 6;
+    const uint32_t ab = j & 1u ? r.b : r.a, cd = j & 1u ? r.d : r.c;
+    const uint32_t sel = j & 2u ? cd : ab;
+    lo = lane_read(sel, x & 63u);
+    if (__builtin_expect((x1 & 63u) != 0u, 1)) {
+        hi = lane_read(sel, x1 & 63u);
+    } else {
+        const uint32_t j1 = x1 >> 6;   // 1..4; 4 (x == top == 255) is replaced by the caller
+        const uint32_t bc = j1 & 1u ? r.b : r.c;
+        hi = lane_read(j1 == 3u ? r.d : bc, 0u);
+    }
+}
+
 template <int NJ>
-__device__ __forceinline__ bool decode_symbol_fast(const Regs<NJ> &row, const ValidLanes<NJ> &valid, uint32_t &low,
+__device__ __forceinline__ bool decode_symbol_fast(const Regs<NJ> &row16, const ValidLanes<NJ> &valid, uint32_t &low,
                                                    uint32_t &high, uint32_t &value, WaveBits &src, int top, bool advance,
                                                    uint32_t &x) {
     const uint32_t range = high - low, d = value - low;
     if (__builtin_expect(d > range, 0)) return false;
-    const Regs<NJ> t = regs_scale(row, range);
+    Regs<NJ> t;
+    if (__builtin_expect(range != 0xFFFFFFFFu, 1)) t = regs_mul_hi(row16, range + 1u);
+    else t = row16;
     const uint32_t rank = regs_rank_valid(t, d, valid);
     uint32_t x1 = rank > 1u ? rank : 1u;   // x + 1
     asm("" : "+s"(x1));                    // keep it scalar: max - 1 would be canonicalised to a VALU-only saturating subtract
     x = x1 - 1u;
     if (advance) {
-        const uint32_t t_lo = regs_fetch(t, x);
-        const uint32_t t_hi = regs_fetch(t, x1);   // x == top: not a table entry, replaced below
+        uint32_t t_lo, t_hi;
+        regs_fetch2(t, x, x1, t_lo, t_hi);   // x == top: t_hi is not a table entry, replaced below
         uint32_t lo = low + t_lo;
         uint32_t hi = x == (uint32_t)top ? high : low - 1u + t_hi;
         // renorm_counts without its n == 32 case (lo != hi here) and without branches: after the common prefix is shifted out
@@ -536,12 +580,11 @@ __device__ __forceinline__ bool decode_symbol_fast(const Regs<NJ> &row, const Va
         low = (lo << m) & 0x7FFFFFFFu;
         high = ~(~hi << m) | 0x80000000u;
         const int c = n + m;
-        if (__builtin_expect(c <= 32, 1)) {
-            const uint32_t bits = src.take(c);
-            value = ((uint32_t)(((uint64_t)value << c)) | bits) ^ (m ? 0x80000000u : 0u);
+        if (__builtin_expect(c <= 32, 1)) {   // ((value << n | bits_n) << m ^ msb) | bits_m  ==  (value << c | bits_c) ^ msb
+            value = src.shift_in(value, c) ^ (m ? 0x80000000u : 0u);
         } else {   // n <= 18 here, m <= 31
-            value = (value << n) | src.take(n);
-            value = ((value << m) ^ 0x80000000u) | src.take(m);
+            value = src.shift_in(value, n);
+            value = src.shift_in(value, m) ^ 0x80000000u;
         }
     }
     return true;
@@ -549,7 +592,7 @@ __device__ __forceinline__ bool decode_symbol_fast(const Regs<NJ> &row, const Va
 
 // lane (i & 63) keeps symbol i until the 64-symbol block is stored with one coalesced write
 __device__ __forceinline__ void keep_symbol(int16_t *dst, uint32_t i, uint32_t n_sym, uint32_t x, int lane, int &kept) {
-    if ((int)(i & 63u) == lane) kept = (int)x;
+    if ((int)(i & 63u) == lane) kept = (int)x;   // (v_writelane_b32 would need two SGPR operands: over gfx9's constant-bus limit)
     if ((i & 63u) == 63u || i == n_sym - 1u) {
         const uint32_t t = (i & ~63u) + (uint32_t)lane;
         if (t <= i) dst[t] = (int16_t)kept;
@@ -628,10 +671,8 @@ __device__ __forceinline__ void lds_row_take(Regs<4> &row, const Regs<4> &pendin
 
 // Coder state of one stream between two chunks of it (l3c_ac_decode_chunk); 32 bytes, opaque to the caller.
 struct DecodeState {
-    uint32_t low, high, value, next;
-    uint64_t acc;
-    int32_t nb;
-    uint32_t pad;
+    uint32_t low, high, value, pos;
+    uint32_t pad[4];
 };
 static_assert(sizeof(DecodeState) == 32, "l3c_ac_decode_state_bytes");
 
@@ -653,6 +694,17 @@ struct DecodeArgs {
     int16_t *sym_out;
     int64_t sym_stride, sym_offset;   // stream s writes sym_out[s * sym_stride + sym_offset + i]
 };
+
+// The same with the entries shifted into the upper half-word (what decode_symbol_fast multiplies with).
+__device__ __forceinline__ void lds_row_take_shifted(Regs<1> &row, const Regs<1> &pending) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %0, 16, %1" : "=&v"(row.a) : "v"(pending.a));
+}
+__device__ __forceinline__ void lds_row_take_shifted(Regs<4> &row, const Regs<4> &pending) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %0, 16, %4\n\tv_lshlrev_b32 %1, 16, %5\n\tv_lshlrev_b32 %2, 16, %6\n\t"
+                 "v_lshlrev_b32 %3, 16, %7"
+                 : "=&v"(row.a), "=&v"(row.b), "=&v"(row.c), "=&v"(row.d)
+                 : "v"(pending.a), "v"(pending.b), "v"(pending.c), "v"(pending.d));
+}
 
 // FAST = true: the loop holds only decode_symbol_fast; a stream that leaves the fast path is marked by the sentinel -1 in the
 // chunk's first output symbol and abandoned (state_out untouched).  FAST = false: the generic decoder, run afterwards for
@@ -713,7 +765,7 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
     uint32_t low = 0, high = 0xFFFFFFFFu, value;
     if (a.state_in) {
         const DecodeState st = a.state_in[s];
-        src.init(words, a.in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES, st.next, st.acc, st.nb);
+        src.init(words, a.in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES, st.pos);
         low = st.low;
         high = st.high;
         value = st.value;
@@ -730,7 +782,8 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
 
     Regs<NJ> row, pending;
     lds_row_issue(block_addr(0), pending);
-    lds_row_take(row, pending);
+    if (FAST) lds_row_take_shifted(row, pending);
+    else lds_row_take(row, pending);
 
     int kept = 0;
     uint32_t i = 0;
@@ -762,7 +815,8 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
             else
                 x = decode_symbol<NJ>(row, low, high, value, src, top, validated, i != no_advance);
             keep_symbol(dst, i, n_sym, x, lane, kept);
-            lds_row_take(row, pending);   // the only take of the loop, on every path (tools/check_asm_prefetch.py)
+            if (FAST) lds_row_take_shifted(row, pending);   // the only take of the loop, on every path
+            else lds_row_take(row, pending);                // (tools/check_asm_prefetch.py)
             if (FAST && __builtin_expect(!ok, 0)) {
                 vm_wait<0>();
                 if (lane == 0) dst[0] = (int16_t)-1;   // same lane, after any block store: the last write to dst[0]
@@ -770,7 +824,7 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
             }
         }
     }
-    if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.next, src.acc, src.nb, 0u};
+    if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.pos, {0u, 0u, 0u, 0u}};
 }
 
 __global__ __launch_bounds__(256) void check_monotone_kernel(const uint16_t *__restrict__ cdf, int64_t n_rows, int Lp,
