@@ -1,2 +1,3 @@
-timeout 900 python -m pytest tests/test_gpu_coder.py tests/test_gpu_net.py -m gpu -q -x --timeout 300 2>&1 | tail -5
-timeout 300 python tools/codec_probe.py --B 8 2>&1 | tail -1
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_dec3 -o dec -- python $GRAFT_REPO_ROOT/tools/codec_probe.py --B 8 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT && python tools/rocpd_summary.py gpurun_out/prof_dec3/dec_results.db gpurun_out/r01_d_decode_kernel_stats.csv 2>&1 | head -12
