@@ -38,7 +38,7 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=6)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=64, help='images per GPU per step')
+    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
     ap.add_argument('--coder-cus', type=int, default=0, help='compute units reserved for the range coder (0 = share all CUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-decode', action='store_true', help='skip the (untimed-region) decode leg')
@@ -201,6 +201,7 @@ def main():
             'bpsp': round(bpsp, 4), 'flop_per_px': ALGO_FLOP_PER_PX,
             'end_to_end_tflops': round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / world, 2),
             'device': '{} ({}, {} CUs)'.format(name, arch, ncu),
+            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
             'roofline': roofline, 'cpu_baseline': cpu, 'decode': decode,
         }
         print(json.dumps(result))
