@@ -284,6 +284,23 @@ int l3c_resample_u8(const uint8_t *in, int64_t planes, int H, int W, int axis, i
 int l3c_u8_to_sym_bn(const uint8_t *in, const float *mean3_host, int64_t B, int64_t HW, int16_t *sym, float *bn,
                      l3c_stream_t stream);
 
+/*
+ * `.l3c` file assembly on the device (the byte format of bitcoding/bitcoding.py:326-375): writes the B files of a batch back
+ * to back into `dst` -- file b at dst + file_offset[b] -- from the coder's per-scale output rows:
+ *     u16 x4 padding | for scale = coarsest .. 0:  u8 C, u16 H, u16 W | per channel: u32 nbytes, payload | 46 E2 84 92
+ *   scales       coarsest first (file order), HOST array; pointers inside are device pointers
+ *   padding      device uint16 [B][4]: left, right, top, bottom          file_offset  device int64 [B]
+ * File b is 8 + sum_scales (5 + 4*C + 4) + its payload bytes long; the caller sizes `dst` and scans the offsets.
+ */
+typedef struct {
+    const uint8_t *out;       /* [B*C][stride], as written by l3c_ac_encode(_groups) */
+    const uint32_t *nbytes;   /* [B*C] */
+    int64_t stride;
+    int C, H, W;
+} l3c_container_scale;
+int l3c_container_write(const l3c_container_scale *scales, int n_scales, int64_t B, const uint16_t *padding,
+                        const int64_t *file_offset, uint8_t *dst, l3c_stream_t stream);
+
 /* symbols -> bottleneck values, to_bn (quantizer.py:44-47): float(S) * bin + x_min, two separately rounded fp32 ops. */
 int l3c_sym_to_bn(const int16_t *sym, int64_t n, float bin_width, float x_min, float *bn, l3c_stream_t stream);
 

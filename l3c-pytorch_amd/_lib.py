@@ -35,6 +35,11 @@ class AcGroup(ctypes.Structure):
                 ('n_streams', c_i64), ('n_sym', c_i64), ('out_stride_bytes', c_i64)]
 
 
+class ContainerScale(ctypes.Structure):
+    """l3c_container_scale (include/l3c_hip.h)."""
+    _fields_ = [('out', c_vp), ('nbytes', c_vp), ('stride', c_i64), ('C', c_int), ('H', c_int), ('W', c_int)]
+
+
 class AcDecodePart(ctypes.Structure):
     """l3c_ac_decode_part (include/l3c_hip.h)."""
     _fields_ = [('cdf', c_vp), ('Lp', c_int), ('in_', c_vp), ('in_offsets', c_vp), ('in_nbytes', c_vp),
@@ -58,6 +63,7 @@ PROTOTYPES = {
     'l3c_ac_encode': (c_int, [c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp]),
     'l3c_ac_encode_groups_workspace_bytes': (c_i64, [c_int, c_i64]),
     'l3c_ac_encode_groups': (c_int, [ctypes.POINTER(AcGroup), c_int, c_vp, c_vp]),
+    'l3c_container_write': (c_int, [ctypes.POINTER(ContainerScale), c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
     'l3c_ac_decode_state_bytes': (c_i64, []),
     'l3c_ac_decode_chunks': (c_int, [ctypes.POINTER(AcDecodePart), c_int, c_vp]),
     'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),

@@ -55,6 +55,19 @@ def uniform_cdf_row(L):
     return cdf.to(torch.int16).reshape(-1)
 
 
+_STAGING = [None]
+
+
+def _staging(nbytes):
+    """Host staging buffer for the D2H copy of finished files: ONE page-locked buffer, grown geometrically and reused (page-
+    locking costs far more than the copy itself); the caller consumes the returned view before the next call."""
+    buf = _STAGING[0]
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 2 * (buf.numel() if buf is not None else 0), 64 << 20), dtype=torch.uint8, pin_memory=True)
+        _STAGING[0] = buf
+    return buf[:nbytes]
+
+
 class EncodedBatch(object):
     """Device-resident result of `Bitcoding.encode_batch`: per scale (coarse -> fine) the coder output of its B*C streams.
     Nothing has been synchronised or copied to the host until `payloads()` / `to_bytes()` is called."""
@@ -97,7 +110,61 @@ class EncodedBatch(object):
         return res
 
     def to_bytes(self, padding_tuples=None):
-        """-> list of B `.l3c` byte strings."""
+        """-> list of B `.l3c` byte strings.  The files are assembled ON THE DEVICE (l3c_container_write: headers, length
+        fields, payloads re-aligned to their byte offsets, all files back to back) and cross PCIe as one copy of exactly
+        their size; the only host work left is cutting the buffer into B bytes objects."""
+        return EncodedBatch.many_to_bytes([self], [padding_tuples])[0]
+
+    def to_host_buffer(self, padding_tuples=None):
+        """-> (uint8 numpy array holding the B files back to back, file offsets, file sizes).  The array is a view of a
+        reused staging buffer: consume it before the next call."""
+        return EncodedBatch.many_to_host_buffer([self], [padding_tuples])
+
+    def _write_container(self, dst, offsets, padding_tuples):
+        """Enqueue the assembly of this batch's files into `dst` at the (device, int64) byte `offsets`."""
+        from .. import _lib
+        B = self.B
+        pads = np.asarray(padding_tuples if padding_tuples else [(0, 0, 0, 0)] * B, dtype=np.uint16).reshape(B, 4)
+        pads = torch.from_numpy(pads.view(np.int16)).cuda()
+        arr = (_lib.ContainerScale * len(self.scales))()
+        for k, (C, H, W, out, nbytes) in enumerate(self.scales):
+            arr[k] = _lib.ContainerScale(ops.ptr(out, torch.uint8), ops.ptr(nbytes, torch.int32), out.shape[1], C, H, W)
+        ops.call('l3c_container_write', arr, len(self.scales), B, ops.ptr(pads), ops.ptr(offsets, torch.int64), ops.ptr(dst),
+                 ops.stream())
+
+    @staticmethod
+    def many_to_host_buffer(encs, padding_lists=None):
+        """The files of several EncodedBatches in ONE device buffer, ONE host synchronisation (their sizes) and ONE D2H copy.
+        -> (uint8 numpy array, file offsets, file sizes); files in the order of `encs`, batch order inside."""
+        for e in encs:
+            e.wait()
+        sizes = torch.cat([e.file_sizes() for e in encs])
+        offs = torch.cumsum(sizes, 0) - sizes
+        sizes_h = sizes.cpu().numpy().astype(np.int64)          # the synchronisation: how many bytes there are
+        total = int(sizes_h.sum())
+        dst = torch.empty(total, dtype=torch.uint8, device='cuda')
+        first = 0
+        for i, e in enumerate(encs):
+            e._write_container(dst, offs[first:first + e.B].contiguous(), padding_lists[i] if padding_lists else None)
+            first += e.B
+        host = _staging(total)
+        host.copy_(dst)
+        torch.cuda.current_stream().synchronize()
+        offs_h = np.concatenate([[0], np.cumsum(sizes_h)[:-1]]).astype(np.int64)
+        return host.numpy(), offs_h, sizes_h
+
+    @staticmethod
+    def many_to_bytes(encs, padding_lists=None):
+        """-> per EncodedBatch the list of its `.l3c` byte strings."""
+        host, offs, sizes = EncodedBatch.many_to_host_buffer(encs, padding_lists)
+        res, k = [], 0
+        for e in encs:
+            res.append([host[offs[k + b]:offs[k + b] + sizes[k + b]].tobytes() for b in range(e.B)])
+            k += e.B
+        return res
+
+    def to_bytes_host_assembled(self, padding_tuples=None):
+        """Reference implementation of `to_bytes` on the host (per-scale copies + Python joins); kept for the tests."""
         pl = self.payloads()
         files = []
         for b in range(self.B):
@@ -227,10 +294,56 @@ class Bitcoding(object):
         `out`: a network output for `imgs` computed earlier (avoids a second forward)."""
         return self.code([self.prepare_batch(imgs, out)])[0]
 
+    N_FORWARD_STREAMS = 3     # used when the HIP runtime was given >= 8 hardware queues, see encode_many
+    N_CODER_GROUPS = 4
+
     def encode_many(self, batches):
         """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries -- images of different sizes
-        cannot share a batch).  Forward + heads of all of them, then ONE grouped coder launch.  -> list of EncodedBatch."""
-        return self.code([self.prepare_batch(x) for x in batches])
+        cannot share a batch).  -> list of EncodedBatch, in the order given.
+        Small batches leave most of the machine idle (one 768x512 image is 192 tiles at the first scale, 12 at the
+        coarsest, for 256 CUs) and their serial coder chains are as long as ever, so
+          * the forward passes + heads of different batches run on N_FORWARD_STREAMS streams side by side, largest
+            batches first -- only if the process runs with GPU_MAX_HW_QUEUES >= 8: with the runtime's default of 4
+            hardware queues the extra streams alias the coder's queue and the long coder kernel stalls them
+            [measured: 64 images of 36 shapes end to end: 42 MPix/s on one stream, 38-43 on three with 4 queues, 52 with 8];
+          * the range coder is launched N_CODER_GROUPS times (one grouped launch per quarter of the set, on the side
+            streams), so that the long chains of the early, large images overlap the later forward passes and only the
+            short chains of the smallest images are left at the end."""
+        if not batches:
+            return []
+        self.blueprint.net._prepare()                  # pack the weights before forking streams
+        order = sorted(range(len(batches)), key=lambda i: -batches[i].shape[0] * batches[i].shape[2] * batches[i].shape[3])
+        main = torch.cuda.current_stream()
+        if int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) >= 8:
+            if getattr(self, '_fwd_streams', None) is None:
+                self._fwd_streams = [torch.cuda.Stream() for _ in range(self.N_FORWARD_STREAMS)]
+            fwd = self._fwd_streams
+        else:
+            fwd = [main]
+        start = torch.cuda.Event()
+        start.record(main)
+        for st in fwd:
+            if st is not main:
+                st.wait_event(start)
+        per_group = -(-len(order) // self.N_CODER_GROUPS)
+        result = [None] * len(batches)
+        pending = []
+        for n, i in enumerate(order):
+            st = fwd[n % len(fwd)]
+            with torch.cuda.stream(st):
+                x = batches[i]
+                if x.is_cuda:
+                    x.record_stream(st)
+                result[i] = self.prepare_batch(x)
+                ev = torch.cuda.Event()
+                ev.record(st)
+            pending.append((result[i], ev))
+            if len(pending) == per_group or n == len(order) - 1:
+                for _, ev in pending:
+                    main.wait_event(ev)            # `code` orders its side stream after the current stream
+                self.code([enc for enc, _ in pending])
+                pending = []
+        return result
 
     def decode_batch(self, files):
         """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU,
@@ -382,8 +495,9 @@ class Bitcoding(object):
             encs = self.encode_many([torch.cat([padded[i] for i in idxs]).to('cuda', torch.float32) for idxs in order])
         comb = auto_crop.CropLossCombinator()
         sizes = {}
-        for idxs, enc in zip(order, encs):
-            for i, data in zip(idxs, enc.to_bytes([pads[i] for i in idxs])):
+        files = EncodedBatch.many_to_bytes(encs, [[pads[i] for i in idxs] for idxs in order])
+        for idxs, datas in zip(order, files):
+            for i, data in zip(idxs, datas):
                 with open(pout + part_suffix_helper.make_part_suffix(i), 'wb') as fout:
                     fout.write(data)
                 sizes[i] = len(data)

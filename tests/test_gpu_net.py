@@ -122,6 +122,22 @@ def test_encode_decode_lossless(blueprint, H, W, B, kind):
     assert len(files[0]) - n_payload == 116
 
 
+def test_device_side_file_assembly_equals_host_assembly(blueprint):
+    """l3c_container_write (headers + length fields + payloads re-aligned to byte offsets, all files of a batch in one
+    buffer) == the byte-by-byte host assembly of the same coder output, with and without padding headers."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.helpers import synthetic
+    bc = Bitcoding(blueprint)
+    for B, H, W in [(1, 8, 8), (3, 40, 24), (5, 64, 96)]:
+        imgs = torch.stack([synthetic.make_image(H, W, 90 + i, ['natural', 'uniform', 'smooth'][i % 3]) for i in range(B)]).long()
+        enc = bc.encode_batch(imgs)
+        pads = [(i, 2 * i, 3, 65535 - i) for i in range(B)]
+        assert enc.to_bytes() == enc.to_bytes_host_assembled()
+        assert enc.to_bytes(pads) == enc.to_bytes_host_assembled(pads)
+        host, offs, sizes = enc.to_host_buffer()
+        assert int(sizes.sum()) == host.size and list(sizes) == enc.file_sizes().cpu().tolist()
+
+
 def test_encode_many_heterogeneous_equals_per_batch(blueprint):
     """encode_many: batches of different shapes share ONE grouped coder launch; bytes equal encode_batch's."""
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding

@@ -14,6 +14,11 @@ import os
 import sys
 import time
 
+# Small, differently shaped batches only fill the machine when several of them run side by side: give the HIP runtime 8
+# hardware queues (default 4) so that Bitcoding.encode_many's forward streams and the coder's side stream do not alias.
+# (bench.py's large batches are 2 % faster with the default, so this is a per-tool setting.)  Must precede HIP start-up.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -66,26 +71,35 @@ def main():
     torch.cuda.synchronize()
 
     t0 = time.perf_counter()
+    marks = {}
     groups = collections.defaultdict(list)
     padded, pads = {}, {}
     for i in mine:
         x, pt = pad.pad(imgs[i].unsqueeze(0), 8, mode='constant')
         padded[i], pads[i] = x, (pt if isinstance(pt, tuple) else (0, 0, 0, 0))
         groups[tuple(x.shape[-2:])].append(i)
+    marks['pad + group (host)'] = time.perf_counter()
     chunks, batches = [], []
     for shape, idxs in groups.items():
         for k in range(0, len(idxs), a.max_batch):
             chunks.append(idxs[k:k + a.max_batch])
             batches.append(torch.cat([padded[i] for i in chunks[-1]]).cuda(non_blocking=True))
+    marks['H2D enqueue'] = time.perf_counter()
     if a.per_batch_coder:
         pending = [(c, bc.encode_batch(b)) for c, b in zip(chunks, batches)]    # one coder launch pair per batch
     else:
         pending = list(zip(chunks, bc.encode_many(batches)))                    # ONE grouped coder launch for the set
+    marks['forward + coder enqueue'] = time.perf_counter()
+    torch.cuda.synchronize()
+    marks['GPU drain'] = time.perf_counter()
     files = {}
-    for chunk, enc in pending:                                       # ... and is collected at the end
-        for i, f in zip(chunk, enc.to_bytes([pads[i] for i in chunk])):
+    from l3c_pytorch_amd.bitcoding.bitcoding import EncodedBatch
+    all_files = EncodedBatch.many_to_bytes([enc for _, enc in pending], [[pads[i] for i in chunk] for chunk, _ in pending])
+    for (chunk, _), fs in zip(pending, all_files):                  # ... and is collected at the end: one sync, one D2H
+        for i, f in zip(chunk, fs):
             files[i] = f
     torch.cuda.synchronize()
+    marks['file assembly + D2H'] = time.perf_counter()
     dt = time.perf_counter() - t0
 
     pixels = sum(sizes[i][0] * sizes[i][1] for i in mine)
@@ -96,6 +110,11 @@ def main():
         print('{} images, {} distinct padded shapes on rank 0, {} launches'.format(a.n, len(groups), len(pending)))
         print('end-to-end encode (host image -> .l3c bytes on the host): {:.2f} MPix/s aggregate over {} rank(s), {:.3f} bpsp, '
               '{:.2f} s'.format(stats['mpix_per_s'], stats['ranks'], stats['bpsp'], stats['seconds']))
+    if rank == 0:
+        prev = t0
+        for k, v in marks.items():
+            print('    {:28s} {:7.1f} ms'.format(k, (v - prev) * 1e3))
+            prev = v
     # spot-check: decode two files
     for i in mine[:2]:
         dec, padding = bc.decode_batch([files[i]])
