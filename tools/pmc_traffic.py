@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""HBM traffic of the dominant conv kernel from rocprofv3 PMC passes -> profiles/r01_pmc_traffic_conv3x3.json.
+
+Run on the GPU box (three SEPARATE passes, counters only with --kernel-trace, as MI355X_MICROARCH.md prescribes):
+
+    cd /tmp && export TMPDIR=/tmp
+    for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+        rocprofv3 --pmc $c --kernel-trace --output-format csv -d OUT/pmc_${c%% *} -- python tools/conv_probe.py --iters 3 --B 128
+    done
+    python tools/pmc_traffic.py OUT 128 > profiles/r01_pmc_traffic_conv3x3.json
+
+Units / corrections (guide, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte
+requests at 64 bytes, so it is doubled; WRITE_SIZE is checked against the algorithmic output bytes.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_launch(out_dir, counter, kernel_substr='conv_lds_kernel'):
+    vals = []
+    for f in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get('Counter_Name') == counter and kernel_substr in row.get('Kernel_Name', ''):
+                vals.append(float(row['Counter_Value']))
+    if not vals:
+        raise SystemExit('no {} samples for {} under {}'.format(counter, kernel_substr, out_dir))
+    # one row per dispatch (or per dispatch and dimension instance: summed by dispatch id would be better; rocprofv3 sums)
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    out_dir, B = sys.argv[1], int(sys.argv[2])
+    H, W, C = 256, 384, 64
+    res = {}
+    for c in ('FETCH_SIZE', 'WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'):
+        res[c], n = per_launch(out_dir, c)
+    algo = B * H * W * C * 4
+    flops = 2.0 * B * H * W * C * C * 9
+    fetch = res['FETCH_SIZE'] * 1024 * 2
+    write = res['WRITE_SIZE'] * 1024
+    print(json.dumps({
+        'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python tools/conv_probe.py '
+                   '--iters 3 --B {}  (three separate passes; tools/pmc_traffic.py)'.format(B),
+        'kernel': 'conv_lds_kernel<3,1> (3x3 64->64, 256x384, batch {})'.format(B),
+        'per_launch': res,
+        'algorithmic_read_bytes': algo, 'algorithmic_write_bytes': algo, 'algorithmic_flops': flops,
+        'hbm_fetch_bytes_corrected_x2': fetch, 'hbm_write_bytes': write, 'hbm_bytes_per_launch': fetch + write,
+        'hbm_bytes_per_flop': (fetch + write) / flops, 'overfetch_vs_algorithmic': fetch / algo,
+        'l2_hit_rate': res['TCC_HIT_sum'] / (res['TCC_HIT_sum'] + res['TCC_MISS_sum']),
+        'note': 'FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE doubled per the guide (128-B requests tallied at 64 B).'}, indent=1))
+
+
+if __name__ == '__main__':
+    main()
