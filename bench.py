@@ -183,7 +183,9 @@ def main():
                         'traffic': traffic, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
                         'algorithmic_gflop_per_launch': round(flops / n / 1e9, 3),
                         'all_mfma_convs': {'achieved': round(all_f / all_s / 1e12, 2), 'seconds_per_step': round(all_s / args.steps, 5),
-                                           'share_of_step': round(all_s / elapsed, 3)}}
+                                           'share_of_step': round(all_s / elapsed, 3)},
+                        'per_kernel': {k: {'tflops': round(v[0] / v[1] / 1e12, 1), 'share_of_step': round(v[1] / elapsed, 3),
+                                           'launches_per_step': v[2] // args.steps} for k, v in sorted(by.items())}}
         decode = None
         if world == 1 and not args.no_decode:
             decode = decode_leg(bc, enc, imgs, compute_stream)

@@ -13,6 +13,7 @@ _CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU c
 # Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
 # appends (kernel key, algorithmic FLOPs, start event, end event), the events being recorded on the launch stream.
 PROFILE = None
+PROFILE_DETAIL = bool(os.environ.get('L3C_PROFILE_DETAIL'))   # split the keys by layer shape (development)
 
 
 # ---- convolution stack ------------------------------------------------------------------------------------------------
@@ -67,6 +68,9 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         e1.record()
         key = ('conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
                'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
+        if PROFILE_DETAIL:
+            key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '',
+                                              ' shuffle' if pixel_shuffle else '')
         PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, e0, e1))
         return out
     call('l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())

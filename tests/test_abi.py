@@ -45,6 +45,46 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.check(rc)
 
 
+def test_argument_validation_of_every_family_precedes_any_launch():
+    """Status codes + messages instead of crashes, checked WITHOUT a GPU: validation happens before any HIP call.  Fake but
+    well-aligned non-null pointers stand in for device memory (they are never dereferenced on these paths)."""
+    import ctypes
+    lib = _lib.load()
+    fake = 0x1000
+
+    def err():
+        return lib.l3c_last_error().decode()
+
+    # range coder
+    assert lib.l3c_ac_decode(fake, 300, 300, fake, fake, fake, 1, 1, 1, fake, None) == -1 and 'Lp out of range' in err()
+    assert lib.l3c_ac_decode(fake, 7, 26, fake, fake, fake, 1, 1, 1, fake, None) == -1 and 'row_stride' in err()
+    assert lib.l3c_ac_decode(fake, 26, 26, fake + 2, fake, fake, 1, 1, 1, fake, None) == -1 and '4-byte aligned' in err()
+    assert lib.l3c_ac_encode(fake, 0, 5, fake, 64, fake, fake, None) == -1
+    assert lib.l3c_ac_encode_groups(None, 1, fake, None) == -1 and 'bad arguments' in err()
+    grp = (_lib.AcGroup * 1)(_lib.AcGroup(fake, fake, fake, 4, 100, 8))        # stride smaller than l3c_ac_max_bytes(100)
+    assert lib.l3c_ac_encode_groups(grp, 1, fake, None) == -1 and 'stride too small' in err()
+    part = _lib.AcDecodePart(fake, 26, fake, fake, fake, 2, 10, None, fake, fake, 0, fake, 10, 0)
+    assert lib.l3c_ac_decode_chunks((_lib.AcDecodePart * 1)(part), 1, None) == -1 and 'must differ' in err()
+    assert lib.l3c_ac_decode_chunks((_lib.AcDecodePart * 1)(part), 9, None) == -1 and 'parts per call' in err()
+    assert lib.l3c_ac_decode_state_bytes() == 32
+    # mixture head
+    assert lib.l3c_dmll_nll(fake, fake, 1, 10, 3, 17, 1, 0.0, 255.0, 256, fake, None) == -1 and 'K out of range' in err()
+    assert lib.l3c_dmll_nll(fake, fake, 1, 10, 5, 10, 1, 0.0, 255.0, 256, fake, None) == -1 and 'C == 3' in err()
+    assert lib.l3c_dmll_cdf_table(fake, None, fake, 1, 10, 3, 10, 1, 1, 0, 10, 257, fake, None, None) == -1 and 'decoded so far' in err()
+    assert lib.l3c_dmll_cdf_table(fake, fake, fake, 1, 10, 3, 10, 1, 1, 5, 10, 257, fake, None, None) == -1 and 'outside the image' in err()
+    assert lib.l3c_dmll_sample(fake, fake, None, 1, 10, 3, 10, 1, fake, None) == -1 and 'null pointer' in err()
+    # convolution
+    assert lib.l3c_conv_pack_weights(fake, 64, 60, 3, fake, None) == -1 and 'multiple of 8' in err()
+    assert lib.l3c_conv_pack_weights(fake, 64, 64, 7, fake, None) == -1 and 'KS must be' in err()
+    # container
+    sc = (_lib.ContainerScale * 1)(_lib.ContainerScale(fake, fake, 6, 5, 8, 8))
+    assert lib.l3c_container_write(sc, 1, 2, fake, fake, fake, None) == -1 and '4-byte aligned' in err()
+    sc = (_lib.ContainerScale * 1)(_lib.ContainerScale(fake, fake, 8, 5, 70000, 8))
+    assert lib.l3c_container_write(sc, 1, 2, fake, fake, fake, None) == -1 and 'u16' in err()
+    assert lib.l3c_container_write(sc, 9, 2, fake, fake, fake, None) == -1 and 'scales' in err()
+    del ctypes
+
+
 def test_no_cpu_fallback():
     import torch
     with pytest.raises(_lib.L3CError):
