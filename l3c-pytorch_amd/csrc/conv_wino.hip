@@ -1,0 +1,433 @@
+// conv_wino.hip -- 3x3 / stride 1 / dilation 1 convolution by Winograd F(2x2, 3x3) on the fp32 MFMA.
+//
+// 2.25x fewer multiplications than the implicit GEMM of conv_mfma.hip: every 2x2 output tile is
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A
+// with d the 4x4 input tile.  The sum over input channels of the element-wise products is, for each of the 16 positions (xi, nu)
+// of the transformed tile, a plain GEMM  M[xi,nu] (tiles x Cout) = V[xi,nu] (tiles x Cin) * U[xi,nu] (Cin x Cout)  -- that part
+// runs on v_mfma_f32_32x32x2_f32; the transforms are a few dozen additions per tile and channel.
+//
+//   * block = 256 threads = 4 wavefronts (one per SIMD) on an 8 x 32 output tile = 4 x 16 = 64 Winograd tiles, 64 output
+//     channels; wavefront w owns 32 tiles (two tile rows) x 32 output channels for ALL 16 positions: 16 accumulator
+//     fragments = 256 registers (the AccVGPR half of the unified file), so the output transform is register-local --
+//     D register r of every fragment belongs to the same (tile, channel);
+//   * input channels in chunks of 8: the raw 10 x 34 patch is register-prefetched two chunks ahead, written to LDS one
+//     chunk ahead, and transformed by all 256 threads (thread = tile x channel pair: 16 ds_read_b64, 32 packed additions,
+//     16 ds_write_b64, bank-conflict-free) into the other V[16][64 tiles][8] buffer WHILE the MFMAs of the current chunk run
+//     -- the slices of the transform are interleaved into the MFMA loop;
+//   * the pre-transformed weights U (l3c_conv_wino_pack_weights: 16/9 of the 3x3 weights, MFMA fragment order) stream through
+//     a double-buffered LDS slab by LDS-DMA, one chunk ahead;
+//   * per position one ds_read_b128 of V and one of U feed four MFMAs (the k-ordering trick of conv_mfma.hip).
+// fp32 throughout; the result differs from the direct convolution by rounding only (transform coefficients are 1, 1/2).
+#include "l3c_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WinoParams {
+    const float *in;
+    const float *u;
+    const float *bias;
+    const float *res;
+    float *out;
+    int in_cstride, in_coff, res_cstride, res_coff, out_cstride, out_coff;
+    int B, H, W, Cin, Cout;
+    int epilogue;
+    int tiles_x, tiles_y, n_chunks_o, total_blocks;
+};
+
+constexpr int WT_H = 8, WT_W = 32;               // output tile of a block
+constexpr int WP_H = WT_H + 2, WP_W = WT_W + 2;  // input patch
+constexpr int WCK = 8;                           // input channels per chunk
+constexpr int PSR = 12;                          // LDS stride of a raw patch pixel (floats)
+constexpr int PSV = 8;                           // LDS stride of a transformed tile (floats), its two 4-float groups swizzled
+constexpr int RAW_FLOATS = WP_H * WP_W * PSR;
+constexpr int V_FLOATS = 16 * 64 * PSV;          // one buffer (two: the next chunk is transformed during the MFMA loop)
+constexpr int U_FLOATS = 16 * 2 * 64 * 4;        // one chunk of one 64-channel output chunk
+constexpr int WINO_LDS_BYTES = (2 * RAW_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS) * 4;   // 163 712 of the CU's 163 840 bytes
+
+__device__ __forceinline__ int xcd_remap_w(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *raw = lds;                            // two buffers: patch of chunk k in raw[k & 1]
+    float *V = lds + 2 * RAW_FLOATS;             // two buffers
+    float *U = V + 2 * V_FLOATS;                 // two buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, lx = lane & 31;
+    const int mi = wave & 1, nj = wave >> 1;
+    const int n_cc = p.Cin / WCK;
+
+    int w = xcd_remap_w(blockIdx.x, p.total_blocks);
+    const int tiles = p.tiles_x * p.tiles_y;
+    const int tile = w % tiles;
+    w /= tiles;
+    const int chunk_o = w % p.n_chunks_o;
+    const int b = w / p.n_chunks_o;
+    const int oy0 = (tile / p.tiles_x) * WT_H, ox0 = (tile % p.tiles_x) * WT_W;
+
+    constexpr int NIT = (WP_H * WP_W * 2 + 255) / 256;
+    constexpr int N_DMA = U_FLOATS / 256 / 4;    // 1 KB DMA pieces of a slab per wave
+    f32x4 stage_regs[NIT];
+    // this thread's patch elements: offsets relative to the image / channel-chunk base, fixed for the whole block
+    int64_t patch_off[NIT];
+    bool patch_ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = tid + it * 256;
+        const int c4 = i & 1, pix = i >> 1;
+        const int r = pix / WP_W, ci = pix % WP_W;
+        const int iy = oy0 - 1 + r, ix = ox0 - 1 + ci;
+        patch_ok[it] = pix < WP_H * WP_W && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        patch_off[it] = ((int64_t)iy * p.W + ix) * p.in_cstride + c4 * 4;
+    }
+    const float *in_b = p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff;
+    const float *u_b = p.u + (size_t)chunk_o * n_cc * U_FLOATS + lane * 4;
+    auto fetch_u_piece = [&](int cc, int k) {   // piece k (0 .. N_DMA-1) of this wave's share of slab cc
+        const int j = wave + 4 * k;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(u_b + (size_t)cc * U_FLOATS + j * 256),
+                                         (__attribute__((address_space(3))) void *)(U + (cc & 1) * U_FLOATS + j * 256), 16, 0, 0);
+    };
+    auto fetch_u = [&](int cc) {
+#pragma unroll
+        for (int k = 0; k < N_DMA; ++k) fetch_u_piece(cc, k);
+    };
+    auto fetch_patch_piece = [&](int cc, int it) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (patch_ok[it]) v = *reinterpret_cast<const f32x4 *>(in_b + cc * WCK + patch_off[it]);
+        stage_regs[it] = v;
+    };
+    auto fetch_patch = [&](int cc) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch_patch_piece(cc, it);
+    };
+    auto store_patch = [&](int cc) {
+        float *dst = raw + (cc & 1) * RAW_FLOATS;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int c4 = i & 1, pix = i >> 1;
+            if (pix < WP_H * WP_W) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = stage_regs[it];
+        }
+    };
+    // Input transform B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]) of this thread's (tile, channel pair): wave w
+    // takes tile row w, lane = (tile column, channel pair) -- 8 tiles x 4 pairs per 32 lanes cover all 64 LDS banks on the
+    // reads (pixel stride 12 floats) and on the writes (tile stride 8 floats).  The two 4-float groups of a tile are swapped
+    // for tiles 8..15 of a row (XOR swizzle), which makes the MFMA A-fragment reads (16 tiles x 16 B per pass) conflict-free.
+    const int t_tx = lane >> 2, t_cq = lane & 3, t_ty = wave;
+    const float *t_src = raw + ((2 * t_ty) * WP_W + 2 * t_tx) * PSR + 2 * t_cq;
+    const int t_dst = (t_ty * 16 + t_tx) * PSV + (((t_cq >> 1) ^ (t_tx >> 3)) * 4) + (t_cq & 1) * 2;
+    f32x2 d[4][4];
+    auto transform_load = [&](int cc, int i) {
+        const float *src = t_src + (cc & 1) * RAW_FLOATS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2 *>(src + (i * WP_W + j) * PSR);
+    };
+    auto transform_rows_col = [&](int j) {   // column j of d <- B^T d
+        const f32x2 b0 = d[0][j] - d[2][j], b1 = d[1][j] + d[2][j], b2 = d[2][j] - d[1][j], b3 = d[1][j] - d[3][j];
+        d[0][j] = b0;
+        d[1][j] = b1;
+        d[2][j] = b2;
+        d[3][j] = b3;
+    };
+    auto transform_rows = [&]() {   // d <- B^T d  (in place, column by column)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 b0 = d[0][j] - d[2][j], b1 = d[1][j] + d[2][j], b2 = d[2][j] - d[1][j], b3 = d[1][j] - d[3][j];
+            d[0][j] = b0;
+            d[1][j] = b1;
+            d[2][j] = b2;
+            d[3][j] = b3;
+        }
+    };
+    auto transform_cols_row = [&](int i) {   // row i of d <- d B
+        const f32x2 c0 = d[i][0] - d[i][2], c1 = d[i][1] + d[i][2], c2 = d[i][2] - d[i][1], c3 = d[i][1] - d[i][3];
+        d[i][0] = c0;
+        d[i][1] = c1;
+        d[i][2] = c2;
+        d[i][3] = c3;
+    };
+    auto transform_write = [&](float *Vdst, int i) {   // finished row i -> positions 4 i .. 4 i + 3
+        float *dst = Vdst + t_dst + (i * 4) * 64 * PSV;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(dst + j * 64 * PSV) = d[i][j];
+    };
+    auto transform_store = [&](float *Vdst, int i) {   // row i of (B^T d) B -> positions 4 i .. 4 i + 3
+        float *dst = Vdst + t_dst + (i * 4) * 64 * PSV;
+        *reinterpret_cast<f32x2 *>(dst + 0 * 64 * PSV) = d[i][0] - d[i][2];
+        *reinterpret_cast<f32x2 *>(dst + 1 * 64 * PSV) = d[i][1] + d[i][2];
+        *reinterpret_cast<f32x2 *>(dst + 2 * 64 * PSV) = d[i][2] - d[i][1];
+        *reinterpret_cast<f32x2 *>(dst + 3 * 64 * PSV) = d[i][1] - d[i][3];
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+
+    // prologue: chunk 0 transformed up front; from then on chunk c + 1 is transformed inside the MFMA loop of chunk c
+    fetch_u(0);
+    fetch_patch(0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); the builtin (not inline asm) so that the compiler's bookkeeping sees it
+    store_patch(0);
+    if (n_cc > 1) fetch_patch(1);   // (slab 1 is requested inside the first MFMA loop)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) transform_load(0, i);
+    transform_rows();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) transform_store(V, i);
+
+    // A fragment of (tile, half): the 4-float group `half`, swizzled like the writes
+    const int a_tile = 32 * mi + lx;
+    const float *a_lane = V + a_tile * PSV + ((half ^ ((a_tile >> 3) & 1)) * 4);
+    for (int cc = 0; cc < n_cc; ++cc) {
+        const bool more = cc + 1 < n_cc;
+        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): patch registers of chunk cc + 1, slab cc + 1 have landed
+        if (more) store_patch(cc + 1);                     // raw[(cc+1) & 1]: last read two loops ago
+        __syncthreads();                                   // the ONE barrier per chunk: V[cc & 1] complete, raw[(cc+1) & 1] and
+                                                           // slab (cc+1) & 1 visible, everyone done with V[(cc+1) & 1], slab cc & 1 ... of cc - 1
+        const bool more2 = cc + 2 < n_cc;
+        const float *a_cur = a_lane + (cc & 1) * V_FLOATS;
+        float *v_next = V + ((cc + 1) & 1) * V_FLOATS;
+        const float *b_lane = U + (cc & 1) * U_FLOATS + nj * 256 + lane * 4;
+        // One wavefront per SIMD: nothing else hides this wave's non-MFMA instructions, and issue is in order -- so they are
+        // dealt out BETWEEN the MFMAs (each keeps the matrix pipe busy for 64 cycles).  Positions are taken in pairs so that
+        // consecutive MFMAs alternate between two accumulators (no back-to-back dependency); the 8 gaps of a pair carry
+        //   0, 1: the A / B fragment reads of the next pair          2, 4: LDS traffic of the next chunk's input transform
+        //   3, 5: its arithmetic                                      6, 7: vector-memory prefetch pieces (patch cc + 2 first:
+        //                                                                   it comes from HBM; then slab cc + 1)
+        f32x4 a0[2], b0[2], a1[2], b1[2];
+        a0[0] = *reinterpret_cast<const f32x4 *>(a_cur);
+        b0[0] = *reinterpret_cast<const f32x4 *>(b_lane);
+        a1[0] = *reinterpret_cast<const f32x4 *>(a_cur + 64 * PSV);
+        b1[0] = *reinterpret_cast<const f32x4 *>(b_lane + 512);
+        auto vmem_piece = [&](int k) {   // k = 0 .. NIT + N_DMA - 1
+            if (k < NIT) {
+                if (more2) fetch_patch_piece(cc + 2, k);
+            } else if (k < NIT + N_DMA) {
+                if (more) fetch_u_piece(cc + 1, k - NIT);
+            }
+        };
+#define L3C_WINO_MFMA(Q, T, A, B)                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], acc[Q], 0, 0, 0);                 \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const int q = 2 * pp, cur = pp & 1, nxt = cur ^ 1;
+            const f32x4 A0 = a0[cur], B0 = b0[cur], A1 = a1[cur], B1 = b1[cur];
+            L3C_WINO_MFMA(q, 0, A0, B0)
+            if (pp < 7) {
+                a0[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 2) * 64 * PSV);
+                b0[nxt] = *reinterpret_cast<const f32x4 *>(b_lane + (q + 2) * 512);
+            }
+            L3C_WINO_MFMA(q + 1, 0, A1, B1)
+            if (pp < 7) {
+                a1[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 3) * 64 * PSV);
+                b1[nxt] = *reinterpret_cast<const f32x4 *>(b_lane + (q + 3) * 512);
+            }
+            L3C_WINO_MFMA(q, 1, A0, B0)
+            if (more) {
+                if (pp < 2) transform_load(cc + 1, 2 * pp);
+                if (pp == 5) transform_write(v_next, 0);
+                if (pp == 6) transform_write(v_next, 2);
+            }
+            L3C_WINO_MFMA(q + 1, 1, A1, B1)
+            if (more) {
+                if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2));
+                if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4));
+            }
+            L3C_WINO_MFMA(q, 2, A0, B0)
+            if (more) {
+                if (pp < 2) transform_load(cc + 1, 2 * pp + 1);
+                if (pp == 5) transform_write(v_next, 1);
+                if (pp == 6) transform_write(v_next, 3);
+            }
+            L3C_WINO_MFMA(q + 1, 2, A1, B1)
+            if (more) {
+                if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2) + 1);
+                if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4) + 1);
+            }
+            L3C_WINO_MFMA(q, 3, A0, B0)
+            vmem_piece(2 * pp);
+            L3C_WINO_MFMA(q + 1, 3, A1, B1)
+            vmem_piece(2 * pp + 1);
+        }
+#undef L3C_WINO_MFMA
+    }
+
+    // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), register-local, + bias / ReLU / residual / store ----
+    const int co = chunk_o * 64 + nj * 32 + lx;
+    if (co >= p.Cout) return;
+    const float bias = p.bias[co];
+    const bool relu = p.epilogue & L3C_EPI_RELU;
+    const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
+    const bool interior = oy0 + WT_H <= p.H && ox0 + WT_W <= p.W;
+    auto y_of = [&](int r, float (&y)[2][2]) {
+        float t0[4], t1[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            t0[nu] = (acc[0 + nu][r] + acc[4 + nu][r]) + acc[8 + nu][r];
+            t1[nu] = (acc[4 + nu][r] - acc[8 + nu][r]) - acc[12 + nu][r];
+        }
+        y[0][0] = (t0[0] + t0[1]) + t0[2];
+        y[0][1] = (t0[1] - t0[2]) - t0[3];
+        y[1][0] = (t1[0] + t1[1]) + t1[2];
+        y[1][1] = (t1[1] - t1[2]) - t1[3];
+    };
+    if (interior && !shuffle) {
+        // tile (ty, tx) of this wave: ty = 2 mi + (r >> 3), tx = (r & 3) + 8 ((r >> 2) & 1) + 4 half -- all offsets are
+        // compile-time multiples of the row / pixel strides on top of one per-lane base
+        const int64_t row = (int64_t)p.W * p.out_cstride;
+        float *obase = p.out + (((size_t)b * p.H + oy0 + 4 * mi) * p.W + ox0 + 8 * half) * p.out_cstride + p.out_coff + co;
+        const int64_t rrow = (int64_t)p.W * p.res_cstride;
+        const float *rbase = p.res ? p.res + (((size_t)b * p.H + oy0 + 4 * mi) * p.W + ox0 + 8 * half) * p.res_cstride + p.res_coff + co
+                                   : nullptr;
+        // all 64 residual values of the lane first (one round trip instead of 64), then transform + store
+        float resv[16][2][2];
+        if (rbase) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ty2 = 2 * (r >> 3), tx2 = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) resv[r][dy][dx] = rbase[(ty2 + dy) * rrow + (tx2 + dx) * p.res_cstride];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float y[2][2];
+            y_of(r, y);
+            const int ty2 = 2 * (r >> 3), tx2 = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float v = y[dy][dx] + bias;
+                    if (relu) v = fmaxf(v, 0.0f);
+                    if (rbase) v = v + resv[r][dy][dx];
+                    obase[(ty2 + dy) * row + (tx2 + dx) * p.out_cstride] = v;
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tl = (r & 3) + 8 * (r >> 2) + 4 * half;       // tile inside this wave's 32
+        const int ty = 2 * mi + (tl >> 4), tx = tl & 15;
+        float y[2][2];
+        y_of(r, y);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int oy = oy0 + 2 * ty + dy, ox = ox0 + 2 * tx + dx;
+                if (oy >= p.H || ox >= p.W) continue;
+                float v = y[dy][dx] + bias;
+                if (relu) v = fmaxf(v, 0.0f);
+                if (p.res) v = v + p.res[(((size_t)b * p.H + oy) * p.W + ox) * p.res_cstride + p.res_coff + co];
+                if (shuffle) {
+                    const size_t oyy = 2 * oy + ((co >> 1) & 1), oxx = 2 * ox + (co & 1);
+                    p.out[(((size_t)b * 2 * p.H + oyy) * 2 * p.W + oxx) * p.out_cstride + p.out_coff + (co >> 2)] = v;
+                } else {
+                    p.out[(((size_t)b * p.H + oy) * p.W + ox) * p.out_cstride + p.out_coff + co] = v;
+                }
+            }
+    }
+}
+
+// OIHW 3x3 weights -> U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) in the kernel's slab order
+// [Cout/64][Cin/8][16 positions][2 n-tiles][64 lanes][4]: lane (n = lane % 32, half = lane / 32), element t holds
+// U[position][co = chunk * 64 + n_tile * 32 + n][ci = cc * 8 + half * 4 + t].
+__global__ __launch_bounds__(256) void pack_wino_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ packed,
+                                                        int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int t = r % 4;  r /= 4;
+        const int lane = r % 64;  r /= 64;
+        const int ntile = r % 2;  r /= 2;
+        const int pos = r % 16;  r /= 16;
+        const int cc = r % (Cin / 8);  r /= (Cin / 8);
+        const int chunk = (int)r;
+        const int co = chunk * 64 + ntile * 32 + (lane & 31);
+        const int ci = cc * 8 + (lane >> 5) * 4 + t;
+        float u = 0.0f;
+        if (co < Cout) {
+            const float *g = w + ((size_t)co * Cin + ci) * 9;
+            const int xi = pos >> 2, nu = pos & 3;
+            float gg[3];   // row xi of G g
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float g0 = g[0 * 3 + j], g1 = g[1 * 3 + j], g2 = g[2 * 3 + j];
+                gg[j] = xi == 0 ? g0 : xi == 3 ? g2 : xi == 1 ? ((g0 + g1) + g2) * 0.5f : ((g0 - g1) + g2) * 0.5f;
+            }
+            u = nu == 0 ? gg[0] : nu == 3 ? gg[2] : nu == 1 ? ((gg[0] + gg[1]) + gg[2]) * 0.5f : ((gg[0] - gg[1]) + gg[2]) * 0.5f;
+        }
+        packed[i] = u;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t l3c_conv_wino_packed_words(int Cout, int Cin) { return (int64_t)((Cout + 63) / 64) * (Cin / 8) * U_FLOATS; }
+
+int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream) {
+    L3C_REQUIRE(w_oihw && packed, "null pointer");
+    L3C_REQUIRE(Cout > 0 && Cin > 0 && Cin % 8 == 0, "Cin must be a multiple of 8");
+    const int64_t total = l3c_conv_wino_packed_words(Cout, Cin);
+    int64_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, l3c::as_stream(stream), w_oihw,
+                       Cout, Cin, packed, total);
+    return l3c::check_launch("pack_wino_kernel");
+}
+
+int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
+    L3C_REQUIRE(d, "null descriptor");
+    L3C_REQUIRE(d->in && d->packed_w && d->bias && d->out, "null pointer in descriptor");
+    L3C_REQUIRE(d->KS == 3 && d->stride == 1 && d->dilation == 1, "Winograd F(2x2,3x3): 3x3, stride 1, dilation 1 only");
+    L3C_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Cout > 0, "bad shape");
+    L3C_REQUIRE(d->Cin > 0 && d->Cin % WCK == 0, "Cin must be a multiple of 8");
+    L3C_REQUIRE(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0, "input channel stride/offset must be multiples of 4");
+    L3C_REQUIRE(d->in_coff + d->Cin <= d->in_cstride, "input channel slice out of range");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || d->residual, "residual epilogue without residual pointer");
+    L3C_REQUIRE(!((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) && (d->epilogue & L3C_EPI_RESIDUAL)), "pixel shuffle + residual not provided");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_PIXEL_SHUFFLE) || d->Cout % 4 == 0, "pixel shuffle needs Cout % 4 == 0");
+    WinoParams p{};
+    p.in = d->in;  p.u = d->packed_w;  p.bias = d->bias;
+    p.res = (d->epilogue & L3C_EPI_RESIDUAL) ? d->residual : nullptr;
+    p.out = d->out;
+    p.in_cstride = d->in_cstride;  p.in_coff = d->in_coff;
+    p.res_cstride = d->res_cstride;  p.res_coff = d->res_coff;
+    p.out_cstride = d->out_cstride;  p.out_coff = d->out_coff;
+    p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = d->Cin;  p.Cout = d->Cout;
+    p.epilogue = d->epilogue;
+    p.tiles_x = (p.W + WT_W - 1) / WT_W;
+    p.tiles_y = (p.H + WT_H - 1) / WT_H;
+    p.n_chunks_o = (p.Cout + 63) / 64;
+    const int64_t total = (int64_t)p.tiles_x * p.tiles_y * p.n_chunks_o * p.B;
+    L3C_REQUIRE(total < (1ll << 31), "grid too large");
+    p.total_blocks = (int)total;
+    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in
+    if (!attr_set) {
+        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES),
+                                      "hipFuncSetAttribute");
+        if (rc != L3C_OK) return rc;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)total), dim3(256), WINO_LDS_BYTES, l3c::as_stream(stream), p);
+    return l3c::check_launch("conv_wino_kernel");
+}
+}

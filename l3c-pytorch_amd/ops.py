@@ -9,6 +9,8 @@ from . import _lib
 from ._lib import ConvDesc, call, ptr, stream
 
 _CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU cross-check kernel (debugging)
+# 3x3 / stride 1 / dilation 1 layers run as Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) unless L3C_CONV_WINO=0
+_CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
 
 # Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
 # appends (kernel key, algorithmic FLOPs, start event, end event), the events being recorded on the launch stream.
@@ -33,6 +35,11 @@ class PackedConv(object):
             n = _lib.load().l3c_conv_packed_words(self.Cout, self.Cin, self.KS)
             self.packed = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_pack_weights', ptr(self.weight), self.Cout, self.Cin, self.KS, ptr(self.packed), stream())
+        self.packed_wino = None
+        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation == 1 and self.Cin % 8 == 0:
+            n = _lib.load().l3c_conv_wino_packed_words(self.Cout, self.Cin)
+            self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
+            call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())
 
     def out_hw(self, H, W):
         pad = self.KS // 2 if self.dilation == 1 else self.dilation
@@ -49,9 +56,10 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         out = (torch.empty(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
                else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
     impl = impl or _CONV_IMPL
+    wino = impl == 'mfma' and layer.packed_wino is not None
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
-    d.packed_w = ptr(layer.packed if impl == 'mfma' else layer.weight)
+    d.packed_w = ptr(layer.packed_wino if wino else layer.packed if impl == 'mfma' else layer.weight)
     d.bias = ptr(layer.bias)
     d.residual = ptr(residual, torch.float32) if residual is not None else None
     d.res_cstride = residual.shape[-1] if residual is not None else 0
@@ -64,16 +72,16 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     if PROFILE is not None and impl == 'mfma':
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call('l3c_conv_mfma', d, stream())
+        call('l3c_conv_wino' if wino else 'l3c_conv_mfma', d, stream())
         e1.record()
-        key = ('conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
+        key = ('conv_wino_kernel' if wino else 'conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
                'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
         if PROFILE_DETAIL:
             key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '',
                                               ' shuffle' if pixel_shuffle else '')
         PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, e0, e1))
         return out
-    call('l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
+    call('l3c_conv_wino' if wino else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
     return out
 
 
