@@ -1,4 +1,4 @@
-// conv_wino.hip -- 3x3 / stride 1 / dilation 1 convolution by Winograd F(2x2, 3x3) on the fp32 MFMA.
+// conv_wino.hip -- 3x3 / stride 1 convolution (dilation 1, 2, 4) by Winograd F(2x2, 3x3) on the fp32 MFMA.
 //
 // 2.25x fewer multiplications than the implicit GEMM of conv_mfma.hip: every 2x2 output tile is
 //     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A
@@ -17,6 +17,7 @@
 //   * the pre-transformed weights U (l3c_conv_wino_pack_weights: 16/9 of the 3x3 weights, MFMA fragment order) stream through
 //     a double-buffered LDS slab by LDS-DMA, one chunk ahead;
 //   * per position one ds_read_b128 of V and one of U feed four MFMAs (the k-ordering trick of conv_mfma.hip).
+// A dilated conv is the dense conv on each of the dil x dil interleaved sub-grids of the image: same kernel, strided indexing.
 // fp32 throughout; the result differs from the direct convolution by rounding only (transform coefficients are 1, 1/2).
 #include "l3c_common.h"
 
@@ -34,6 +35,7 @@ struct WinoParams {
     float *out;
     int in_cstride, in_coff, res_cstride, res_coff, out_cstride, out_coff;
     int B, H, W, Cin, Cout;
+    int dil;          // 1, 2 or 4: the output grid splits into dil x dil interleaved sub-grids, each an ordinary 3x3 conv
     int epilogue;
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
 };
@@ -69,9 +71,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int tiles = p.tiles_x * p.tiles_y;
     const int tile = w % tiles;
     w /= tiles;
+    const int phase = w % (p.dil * p.dil);   // which of the dil x dil sub-grids (dilated conv = dense conv on each of them)
+    w /= p.dil * p.dil;
     const int chunk_o = w % p.n_chunks_o;
     const int b = w / p.n_chunks_o;
-    const int oy0 = (tile / p.tiles_x) * WT_H, ox0 = (tile % p.tiles_x) * WT_W;
+    const int dil = p.dil, py = phase / dil, px = phase % dil;
+    const int sy0 = (tile / p.tiles_x) * WT_H, sx0 = (tile % p.tiles_x) * WT_W;   // tile origin in sub-grid coordinates
 
     constexpr int NIT = (WP_H * WP_W * 2 + 255) / 256;
     constexpr int N_DMA = U_FLOATS / 256 / 4;    // 1 KB DMA pieces of a slab per wave
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         const int i = tid + it * 256;
         const int c4 = i & 1, pix = i >> 1;
         const int r = pix / WP_W, ci = pix % WP_W;
-        const int iy = oy0 - 1 + r, ix = ox0 - 1 + ci;
+        const int iy = py + dil * (sy0 - 1 + r), ix = px + dil * (sx0 - 1 + ci);
         patch_ok[it] = pix < WP_H * WP_W && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         patch_off[it] = ((int64_t)iy * p.W + ix) * p.in_cstride + c4 * 4;
     }
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const float bias = p.bias[co];
     const bool relu = p.epilogue & L3C_EPI_RELU;
     const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
-    const bool interior = oy0 + WT_H <= p.H && ox0 + WT_W <= p.W;
+    const bool interior = py + dil * (sy0 + WT_H - 1) < p.H && px + dil * (sx0 + WT_W - 1) < p.W;
     auto y_of = [&](int r, float (&y)[2][2]) {
         float t0[4], t1[4];
 #pragma unroll
@@ -287,11 +292,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     if (interior && !shuffle) {
         // tile (ty, tx) of this wave: ty = 2 mi + (r >> 3), tx = (r & 3) + 8 ((r >> 2) & 1) + 4 half -- all offsets are
         // compile-time multiples of the row / pixel strides on top of one per-lane base
-        const int64_t row = (int64_t)p.W * p.out_cstride;
-        float *obase = p.out + (((size_t)b * p.H + oy0 + 4 * mi) * p.W + ox0 + 8 * half) * p.out_cstride + p.out_coff + co;
-        const int64_t rrow = (int64_t)p.W * p.res_cstride;
-        const float *rbase = p.res ? p.res + (((size_t)b * p.H + oy0 + 4 * mi) * p.W + ox0 + 8 * half) * p.res_cstride + p.res_coff + co
-                                   : nullptr;
+        const int oyb = py + dil * (sy0 + 4 * mi), oxb = px + dil * (sx0 + 8 * half);
+        const int64_t row = (int64_t)dil * p.W * p.out_cstride, col = (int64_t)dil * p.out_cstride;
+        float *obase = p.out + (((size_t)b * p.H + oyb) * p.W + oxb) * p.out_cstride + p.out_coff + co;
+        const int64_t rrow = (int64_t)dil * p.W * p.res_cstride, rcol = (int64_t)dil * p.res_cstride;
+        const float *rbase = p.res ? p.res + (((size_t)b * p.H + oyb) * p.W + oxb) * p.res_cstride + p.res_coff + co : nullptr;
         // all 64 residual values of the lane first (one round trip instead of 64), then transform + store
         float resv[16][2][2];
         if (rbase) {
@@ -301,7 +306,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) resv[r][dy][dx] = rbase[(ty2 + dy) * rrow + (tx2 + dx) * p.res_cstride];
+                    for (int dx = 0; dx < 2; ++dx) resv[r][dy][dx] = rbase[(ty2 + dy) * rrow + (tx2 + dx) * rcol];
             }
         }
 #pragma unroll
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                     float v = y[dy][dx] + bias;
                     if (relu) v = fmaxf(v, 0.0f);
                     if (rbase) v = v + resv[r][dy][dx];
-                    obase[(ty2 + dy) * row + (tx2 + dx) * p.out_cstride] = v;
+                    obase[(ty2 + dy) * row + (tx2 + dx) * col] = v;
                 }
         }
         return;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
-                const int oy = oy0 + 2 * ty + dy, ox = ox0 + 2 * tx + dx;
+                const int oy = py + dil * (sy0 + 2 * ty + dy), ox = px + dil * (sx0 + 2 * tx + dx);
                 if (oy >= p.H || ox >= p.W) continue;
                 float v = y[dy][dx] + bias;
                 if (relu) v = fmaxf(v, 0.0f);
@@ -396,7 +401,9 @@ int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *pa
 int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     L3C_REQUIRE(d, "null descriptor");
     L3C_REQUIRE(d->in && d->packed_w && d->bias && d->out, "null pointer in descriptor");
-    L3C_REQUIRE(d->KS == 3 && d->stride == 1 && d->dilation == 1, "Winograd F(2x2,3x3): 3x3, stride 1, dilation 1 only");
+    L3C_REQUIRE(d->KS == 3 && d->stride == 1, "Winograd F(2x2,3x3): 3x3, stride 1 only");
+    L3C_REQUIRE(d->dilation == 1 || d->dilation == 2 || d->dilation == 4, "dilation must be 1, 2 or 4");
+    L3C_REQUIRE(d->dilation == 1 || !(d->epilogue & L3C_EPI_PIXEL_SHUFFLE), "pixel shuffle with dilation not provided");
     L3C_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Cout > 0, "bad shape");
     L3C_REQUIRE(d->Cin > 0 && d->Cin % WCK == 0, "Cin must be a multiple of 8");
     L3C_REQUIRE(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0, "input channel stride/offset must be multiples of 4");
@@ -413,10 +420,11 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     p.out_cstride = d->out_cstride;  p.out_coff = d->out_coff;
     p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = d->Cin;  p.Cout = d->Cout;
     p.epilogue = d->epilogue;
-    p.tiles_x = (p.W + WT_W - 1) / WT_W;
-    p.tiles_y = (p.H + WT_H - 1) / WT_H;
+    p.dil = d->dilation;
+    p.tiles_x = ((p.W + p.dil - 1) / p.dil + WT_W - 1) / WT_W;   // tiles of the (largest) sub-grid
+    p.tiles_y = ((p.H + p.dil - 1) / p.dil + WT_H - 1) / WT_H;
     p.n_chunks_o = (p.Cout + 63) / 64;
-    const int64_t total = (int64_t)p.tiles_x * p.tiles_y * p.n_chunks_o * p.B;
+    const int64_t total = (int64_t)p.tiles_x * p.tiles_y * p.dil * p.dil * p.n_chunks_o * p.B;
     L3C_REQUIRE(total < (1ll << 31), "grid too large");
     p.total_blocks = (int)total;
     static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in

@@ -9,7 +9,7 @@ from . import _lib
 from ._lib import ConvDesc, call, ptr, stream
 
 _CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU cross-check kernel (debugging)
-# 3x3 / stride 1 / dilation 1 layers run as Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) unless L3C_CONV_WINO=0
+# 3x3 / stride 1 layers (dilation 1, 2, 4) run as Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) unless L3C_CONV_WINO=0
 _CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
 
 # Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
@@ -36,7 +36,7 @@ class PackedConv(object):
             self.packed = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_pack_weights', ptr(self.weight), self.Cout, self.Cin, self.KS, ptr(self.packed), stream())
         self.packed_wino = None
-        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation == 1 and self.Cin % 8 == 0:
+        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 8 == 0:
             n = _lib.load().l3c_conv_wino_packed_words(self.Cout, self.Cin)
             self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())
