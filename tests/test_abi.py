@@ -76,6 +76,16 @@ def test_argument_validation_of_every_family_precedes_any_launch():
     # convolution
     assert lib.l3c_conv_pack_weights(fake, 64, 60, 3, fake, None) == -1 and 'multiple of 8' in err()
     assert lib.l3c_conv_pack_weights(fake, 64, 64, 7, fake, None) == -1 and 'KS must be' in err()
+    d = _lib.ConvDesc()
+    d.inp = d.packed_w = d.bias = d.out = fake
+    d.B, d.Hin, d.Win, d.Cin, d.Cout, d.KS, d.stride, d.dilation = 1, 8, 8, 64, 64, 5, 1, 1
+    d.in_cstride = 64
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '3x3, stride 1 only' in err()
+    d.KS, d.dilation = 3, 3
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'dilation must be' in err()
+    d.dilation, d.Cin = 1, 60
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 8' in err()
+    assert lib.l3c_conv_wino_packed_words(64, 64) == 16 * 64 * 64 and lib.l3c_conv_wino_packed_words(120, 64) == 16 * 128 * 64
     # container
     sc = (_lib.ContainerScale * 1)(_lib.ContainerScale(fake, fake, 6, 5, 8, 8))
     assert lib.l3c_container_write(sc, 1, 2, fake, fake, fake, None) == -1 and '4-byte aligned' in err()

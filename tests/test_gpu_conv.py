@@ -1,4 +1,4 @@
-"""-m gpu: the conv stack kernels (csrc/conv_mfma.hip, csrc/conv_small.hip) against a plain torch fp32 reference of
+"""-m gpu: the conv stack kernels (csrc/conv_mfma.hip, csrc/conv_wino.hip, csrc/conv_small.hip) against a plain torch fp32 reference of
 the same op (F.conv2d on the CPU) and against the VALU cross-check kernel.  Floating point: tolerance stated per test."""
 import numpy as np
 import pytest
@@ -142,3 +142,57 @@ def test_sym_to_bn_bit_exact():
     assert torch.equal(got, quantizer.to_bn(sym, -1, 1, 25))
     sym = torch.arange(256, dtype=torch.int16)
     assert torch.equal(ops.sym_to_bn(sym.cuda(), 1.0, 0).cpu(), sym.float())
+
+
+WINO_CASES = [
+    # dil, Cin, Cout, B, H, W, relu, residual, shuffle
+    (1, 64, 64, 1, 8, 32, False, False, False),        # exactly one 8x32 block tile
+    (1, 64, 64, 2, 13, 45, True, False, False),        # ragged
+    (1, 64, 64, 3, 50, 70, False, True, False),        # residual, interior + edge tiles
+    (1, 64, 256, 2, 24, 40, False, False, True),       # the PixelShuffle tail
+    (1, 64, 120, 1, 17, 33, True, False, False),       # Cout not a multiple of 32
+    (2, 64, 64, 2, 19, 37, False, True, False),        # dilated: dense conv on the 2x2 interleaved sub-grids
+    (4, 64, 64, 1, 21, 50, True, False, False),
+    (4, 64, 64, 1, 3, 5, False, False, False),         # image smaller than the dilation pattern
+    (1, 8, 64, 1, 9, 9, False, False, False),          # a single input-channel chunk
+    (1, 64, 64, 1, 1, 1, False, False, False),
+]
+
+
+@pytest.mark.parametrize('dil,Cin,Cout,B,H,W,relu,res,shuffle', WINO_CASES)
+def test_winograd_conv_vs_implicit_gemm_and_fp64(dil, Cin, Cout, B, H, W, relu, res, shuffle):
+    """Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) against the implicit-GEMM kernel and an fp64 reference.
+    Same fp32 data, different (shorter) summation chains: both sit within 3e-5 of fp64 for unit-scale data, Winograd is
+    usually the closer one; determinism and batch invariance are exact."""
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(dil * 1000 + H * 10 + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), dilation=dil, padding=dil)
+    if relu:
+        ref = ref.clamp(min=0)
+    if res:
+        ref = ref + r.double()
+    if shuffle:
+        ref = F.pixel_shuffle(ref, 2)
+    layer = ops.PackedConv(w, b, dilation=dil)
+    assert layer.packed_wino is not None
+    kw = dict(relu=relu, residual=_nhwc(r).cuda() if res else None, pixel_shuffle=shuffle)
+    got = ops.conv(_nhwc(x).cuda(), layer, **kw).cpu().permute(0, 3, 1, 2)          # dispatches to l3c_conv_wino
+    assert got.shape == ref.shape
+    assert (got.double() - ref).abs().max().item() < 3e-5
+    if Cin % 16 == 0:
+        wino = layer.packed_wino
+        layer.packed_wino = None                                                       # same layer through l3c_conv_mfma
+        gemm = ops.conv(_nhwc(x).cuda(), layer, **kw).cpu().permute(0, 3, 1, 2)
+        layer.packed_wino = wino
+        assert (gemm.double() - ref).abs().max().item() < 3e-5
+        assert (got - gemm).abs().max().item() < 3e-5
+    again = ops.conv(_nhwc(x).cuda(), layer, **kw).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, again)
+    if B > 1:
+        kw1 = dict(kw, residual=_nhwc(r[1:2]).cuda() if res else None)
+        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, **kw1).cpu().permute(0, 3, 1, 2)
+        assert torch.equal(single, got[1:2])

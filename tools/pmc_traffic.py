@@ -7,7 +7,7 @@ Run on the GPU box (three SEPARATE passes, counters only with --kernel-trace, as
     for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
         rocprofv3 --pmc $c --kernel-trace --output-format csv -d OUT/pmc_${c%% *} -- python tools/conv_probe.py --iters 3 --B 128
     done
-    python tools/pmc_traffic.py OUT 128 > profiles/r01_pmc_traffic_conv3x3.json
+    python tools/pmc_traffic.py OUT 128 [kernel-name substring, default conv_wino_kernel] > profiles/r01_pmc_traffic_conv3x3.json
 
 Units / corrections (guide, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies 128-byte
 requests at 64 bytes, so it is doubled; WRITE_SIZE is checked against the algorithmic output bytes.
@@ -19,7 +19,7 @@ import os
 import sys
 
 
-def per_launch(out_dir, counter, kernel_substr='conv_lds_kernel'):
+def per_launch(out_dir, counter, kernel_substr):
     vals = []
     for f in glob.glob(os.path.join(out_dir, '**', '*counter_collection.csv'), recursive=True):
         for row in csv.DictReader(open(f)):
@@ -33,10 +33,11 @@ def per_launch(out_dir, counter, kernel_substr='conv_lds_kernel'):
 
 def main():
     out_dir, B = sys.argv[1], int(sys.argv[2])
+    kernel = sys.argv[3] if len(sys.argv) > 3 else 'conv_wino_kernel'
     H, W, C = 256, 384, 64
     res = {}
     for c in ('FETCH_SIZE', 'WRITE_SIZE', 'TCC_HIT_sum', 'TCC_MISS_sum'):
-        res[c], n = per_launch(out_dir, c)
+        res[c], n = per_launch(out_dir, c, kernel)
     algo = B * H * W * C * 4
     flops = 2.0 * B * H * W * C * C * 9
     fetch = res['FETCH_SIZE'] * 1024 * 2
@@ -44,7 +45,7 @@ def main():
     print(json.dumps({
         'command': 'rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE|TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python tools/conv_probe.py '
                    '--iters 3 --B {}  (three separate passes; tools/pmc_traffic.py)'.format(B),
-        'kernel': 'conv_lds_kernel<3,1> (3x3 64->64, 256x384, batch {})'.format(B),
+        'kernel': '{} (3x3 64->64, 256x384, batch {})'.format(kernel, B),
         'per_launch': res,
         'algorithmic_read_bytes': algo, 'algorithmic_write_bytes': algo, 'algorithmic_flops': flops,
         'hbm_fetch_bytes_corrected_x2': fetch, 'hbm_write_bytes': write, 'hbm_bytes_per_launch': fetch + write,
