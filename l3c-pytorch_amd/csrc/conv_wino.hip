@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) fetch_patch_piece(cc, it);
     };
+    static_assert((WP_H * WP_W * 2 + 255) / 256 + U_FLOATS / 256 / 4 <= 12, "prefetch pieces must fit the gaps of pairs 0..3");
     auto store_patch = [&](int cc) {
         float *dst = raw + (cc & 1) * RAW_FLOATS;
 #pragma unroll
@@ -178,43 +179,48 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
 
-    // prologue: chunk 0 transformed up front; from then on chunk c + 1 is transformed inside the MFMA loop of chunk c
+    // Prologue.  Invariants at the start of the MFMA loop of chunk c:  V[c & 1] and slab c & 1 complete and visible; the operand
+    // fragments of its first position pair loaded; raw[(c+1) & 1] = patch of chunk c + 1, visible; the staging registers free.
     fetch_u(0);
     fetch_patch(0);
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); the builtin (not inline asm) so that the compiler's bookkeeping sees it
     store_patch(0);
-    if (n_cc > 1) fetch_patch(1);   // (slab 1 is requested inside the first MFMA loop)
+    if (n_cc > 1) fetch_patch(1);
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) transform_load(0, i);
     transform_rows();
 #pragma unroll
     for (int i = 0; i < 4; ++i) transform_store(V, i);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    if (n_cc > 1) store_patch(1);
+    __syncthreads();
 
     // A fragment of (tile, half): the 4-float group `half`, swizzled like the writes
     const int a_tile = 32 * mi + lx;
     const float *a_lane = V + a_tile * PSV + ((half ^ ((a_tile >> 3) & 1)) * 4);
+    const float *b_lane0 = U + nj * 256 + lane * 4;
+    // One wavefront per SIMD: nothing else hides this wave's non-MFMA instructions, and issue is in order -- so they are
+    // dealt out BETWEEN the MFMAs (each keeps the matrix pipe busy for 64 cycles).  Positions are taken in pairs so that
+    // consecutive MFMAs alternate between two accumulators; the 8 gaps of a pair carry
+    //   0, 1: the A / B fragment reads of the next pair          2, 4: LDS traffic of the next chunk's input transform
+    //   3, 5: its arithmetic (pairs 0, 1: more prefetch pieces)   6, 7: vector-memory prefetch pieces (patch c + 2 first:
+    //                                                                   it comes from HBM; then slab c + 1)
+    // The chunk's ONE barrier sits between its pairs 6 and 7: by then this wave has written its share of V[(c+1) & 1], stored
+    // the patch of chunk c + 2 and loaded the operands of pair 7, so the last pair's 8 MFMAs run while the barrier releases
+    // and the first fragments of chunk c + 1 arrive -- the matrix pipe does not drain at the chunk boundary.
+    f32x4 a0[2], b0[2], a1[2], b1[2];
+    a0[0] = *reinterpret_cast<const f32x4 *>(a_lane);
+    b0[0] = *reinterpret_cast<const f32x4 *>(b_lane0);
+    a1[0] = *reinterpret_cast<const f32x4 *>(a_lane + 64 * PSV);
+    b1[0] = *reinterpret_cast<const f32x4 *>(b_lane0 + 512);
     for (int cc = 0; cc < n_cc; ++cc) {
-        const bool more = cc + 1 < n_cc;
-        __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): patch registers of chunk cc + 1, slab cc + 1 have landed
-        if (more) store_patch(cc + 1);                     // raw[(cc+1) & 1]: last read two loops ago
-        __syncthreads();                                   // the ONE barrier per chunk: V[cc & 1] complete, raw[(cc+1) & 1] and
-                                                           // slab (cc+1) & 1 visible, everyone done with V[(cc+1) & 1], slab cc & 1 ... of cc - 1
-        const bool more2 = cc + 2 < n_cc;
+        const bool more = cc + 1 < n_cc, more2 = cc + 2 < n_cc;
         const float *a_cur = a_lane + (cc & 1) * V_FLOATS;
+        const float *a_nxt = a_lane + ((cc + 1) & 1) * V_FLOATS;
         float *v_next = V + ((cc + 1) & 1) * V_FLOATS;
-        const float *b_lane = U + (cc & 1) * U_FLOATS + nj * 256 + lane * 4;
-        // One wavefront per SIMD: nothing else hides this wave's non-MFMA instructions, and issue is in order -- so they are
-        // dealt out BETWEEN the MFMAs (each keeps the matrix pipe busy for 64 cycles).  Positions are taken in pairs so that
-        // consecutive MFMAs alternate between two accumulators (no back-to-back dependency); the 8 gaps of a pair carry
-        //   0, 1: the A / B fragment reads of the next pair          2, 4: LDS traffic of the next chunk's input transform
-        //   3, 5: its arithmetic                                      6, 7: vector-memory prefetch pieces (patch cc + 2 first:
-        //                                                                   it comes from HBM; then slab cc + 1)
-        f32x4 a0[2], b0[2], a1[2], b1[2];
-        a0[0] = *reinterpret_cast<const f32x4 *>(a_cur);
-        b0[0] = *reinterpret_cast<const f32x4 *>(b_lane);
-        a1[0] = *reinterpret_cast<const f32x4 *>(a_cur + 64 * PSV);
-        b1[0] = *reinterpret_cast<const f32x4 *>(b_lane + 512);
+        const float *b_lane = b_lane0 + (cc & 1) * U_FLOATS;
+        const float *b_nxt = b_lane0 + ((cc + 1) & 1) * U_FLOATS;
         auto vmem_piece = [&](int k) {   // k = 0 .. NIT + N_DMA - 1
             if (k < NIT) {
                 if (more2) fetch_patch_piece(cc + 2, k);
@@ -230,6 +236,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         for (int pp = 0; pp < 8; ++pp) {
             const int q = 2 * pp, cur = pp & 1, nxt = cur ^ 1;
             const f32x4 A0 = a0[cur], B0 = b0[cur], A1 = a1[cur], B1 = b1[cur];
+            if (pp == 7) {
+                // everything chunk c + 1 needs from this wave is issued: patch c + 2 stored, V[(c+1) & 1] written, slab c + 1
+                // requested -- wait for the memory operations, then the barrier, then fetch the first fragments of chunk c + 1
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __syncthreads();
+                if (more) {
+                    a0[nxt] = *reinterpret_cast<const f32x4 *>(a_nxt);
+                    b0[nxt] = *reinterpret_cast<const f32x4 *>(b_nxt);
+                    a1[nxt] = *reinterpret_cast<const f32x4 *>(a_nxt + 64 * PSV);
+                    b1[nxt] = *reinterpret_cast<const f32x4 *>(b_nxt + 512);
+                }
+            }
             L3C_WINO_MFMA(q, 0, A0, B0)
             if (pp < 7) {
                 a0[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 2) * 64 * PSV);
@@ -247,6 +265,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 if (pp == 6) transform_write(v_next, 2);
             }
             L3C_WINO_MFMA(q + 1, 1, A1, B1)
+            if (pp < 2) vmem_piece(4 * pp);
             if (more) {
                 if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2));
                 if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4));
@@ -258,14 +277,18 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 if (pp == 6) transform_write(v_next, 3);
             }
             L3C_WINO_MFMA(q + 1, 2, A1, B1)
+            if (pp < 2) vmem_piece(4 * pp + 1);
             if (more) {
                 if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2) + 1);
                 if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4) + 1);
             }
             L3C_WINO_MFMA(q, 3, A0, B0)
-            vmem_piece(2 * pp);
+            if (pp < 2) vmem_piece(4 * pp + 2);
+            else if (pp < 4) vmem_piece(8 + 2 * (pp - 2));
+            if (pp == 5 && more2) store_patch(cc + 2);   // raw[c & 1]: read by the transform of chunk c during loop c - 1
             L3C_WINO_MFMA(q + 1, 3, A1, B1)
-            vmem_piece(2 * pp + 1);
+            if (pp < 2) vmem_piece(4 * pp + 3);
+            else if (pp < 4) vmem_piece(8 + 2 * (pp - 2) + 1);
         }
 #undef L3C_WINO_MFMA
     }
