@@ -47,8 +47,8 @@ constexpr int PSR = 12;                          // LDS stride of a raw patch pi
 constexpr int PSV = 8;                           // LDS stride of a transformed tile (floats), its two 4-float groups swizzled
 constexpr int RAW_FLOATS = WP_H * WP_W * PSR;
 constexpr int V_FLOATS = 16 * 64 * PSV;          // one buffer (two: the next chunk is transformed during the MFMA loop)
-constexpr int U_FLOATS = 16 * 2 * 64 * 4;        // one chunk of one 64-channel output chunk
-constexpr int WINO_LDS_BYTES = (2 * RAW_FLOATS + 2 * V_FLOATS + 2 * U_FLOATS) * 4;   // 163 712 of the CU's 163 840 bytes
+constexpr int U_FLOATS = 16 * 2 * 64 * 4;        // packed weights of one input chunk x one 64-channel output chunk
+constexpr int WINO_LDS_BYTES = (2 * RAW_FLOATS + 2 * V_FLOATS) * 4;   // 98 176 bytes
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
     const int q = total >> 3, r = total & 7;
@@ -60,7 +60,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *raw = lds;                            // two buffers: patch of chunk k in raw[k & 1]
     float *V = lds + 2 * RAW_FLOATS;             // two buffers
-    float *U = V + 2 * V_FLOATS;                 // two buffers
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, lx = lane & 31;
@@ -79,7 +78,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int sy0 = (tile / p.tiles_x) * WT_H, sx0 = (tile % p.tiles_x) * WT_W;   // tile origin in sub-grid coordinates
 
     constexpr int NIT = (WP_H * WP_W * 2 + 255) / 256;
-    constexpr int N_DMA = U_FLOATS / 256 / 4;    // 1 KB DMA pieces of a slab per wave
     f32x4 stage_regs[NIT];
     // this thread's patch elements: offsets relative to the image / channel-chunk base, fixed for the whole block
     int64_t patch_off[NIT];
@@ -91,36 +89,37 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         const int r = pix / WP_W, ci = pix % WP_W;
         const int iy = py + dil * (sy0 - 1 + r), ix = px + dil * (sx0 - 1 + ci);
         patch_ok[it] = pix < WP_H * WP_W && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        patch_off[it] = ((int64_t)iy * p.W + ix) * p.in_cstride + c4 * 4;
+        patch_off[it] = patch_ok[it] ? ((int64_t)iy * p.W + ix) * p.in_cstride + c4 * 4 : 0;   // padding: any valid address
     }
     const float *in_b = p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff;
-    const float *u_b = p.u + (size_t)chunk_o * n_cc * U_FLOATS + lane * 4;
-    auto fetch_u_piece = [&](int cc, int k) {   // piece k (0 .. N_DMA-1) of this wave's share of slab cc
-        const int j = wave + 4 * k;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(u_b + (size_t)cc * U_FLOATS + j * 256),
-                                         (__attribute__((address_space(3))) void *)(U + (cc & 1) * U_FLOATS + j * 256), 16, 0, 0);
+    // B operands (transformed weights): the packed layout IS the MFMA fragment order, so position q of chunk cc is ONE
+    // coalesced 16-byte load per lane straight into the operand registers (uniform base + per-lane offset) -- no LDS staging.
+    // Buffer addressing: uniform descriptor + per-lane byte offset (fixed) + scalar offset -- no vector address arithmetic.
+    // Every load inside the chunk loop is UNCONDITIONAL (the last chunks re-request a slice they already have): a load
+    // behind a branch would make the compiler's count of outstanding loads imprecise and turn its waits into vmcnt(0).
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u + (size_t)chunk_o * n_cc * U_FLOATS), 0,
+                                                          n_cc * U_FLOATS * 4, 0x00020000);
+    const int u_lane = (nj * 256 + lane * 4) * 4;
+    f32x4 bq[16];
+    auto fetch_b = [&](int cc, int q) {
+        bq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (cc * U_FLOATS + q * 512) * 4, 0));
     };
-    auto fetch_u = [&](int cc) {
-#pragma unroll
-        for (int k = 0; k < N_DMA; ++k) fetch_u_piece(cc, k);
-    };
-    auto fetch_patch_piece = [&](int cc, int it) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (patch_ok[it]) v = *reinterpret_cast<const f32x4 *>(in_b + cc * WCK + patch_off[it]);
-        stage_regs[it] = v;
+    auto fetch_patch_piece = [&](int cc, int it) {   // zero padding is applied by store_patch
+        stage_regs[it] = *reinterpret_cast<const f32x4 *>(in_b + cc * WCK + patch_off[it]);
     };
     auto fetch_patch = [&](int cc) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) fetch_patch_piece(cc, it);
     };
-    static_assert((WP_H * WP_W * 2 + 255) / 256 + U_FLOATS / 256 / 4 <= 12, "prefetch pieces must fit the gaps of pairs 0..3");
+    static_assert(NIT == 3, "the patch prefetch pieces are dealt out by hand below");
     auto store_patch = [&](int cc) {
         float *dst = raw + (cc & 1) * RAW_FLOATS;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
             const int c4 = i & 1, pix = i >> 1;
-            if (pix < WP_H * WP_W) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = stage_regs[it];
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            if (pix < WP_H * WP_W) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = patch_ok[it] ? stage_regs[it] : zero;
         }
     };
     // Input transform B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]) of this thread's (tile, channel pair): wave w
@@ -181,9 +180,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 
     // Prologue.  Invariants at the start of the MFMA loop of chunk c:  V[c & 1] and slab c & 1 complete and visible; the operand
     // fragments of its first position pair loaded; raw[(c+1) & 1] = patch of chunk c + 1, visible; the staging registers free.
-    fetch_u(0);
     fetch_patch(0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); the builtin (not inline asm) so that the compiler's bookkeeping sees it
+#pragma unroll
+    for (int q = 0; q < 16; ++q) fetch_b(0, q);
     store_patch(0);
     if (n_cc > 1) fetch_patch(1);
     __syncthreads();
@@ -192,42 +191,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     transform_rows();
 #pragma unroll
     for (int i = 0; i < 4; ++i) transform_store(V, i);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
     if (n_cc > 1) store_patch(1);
     __syncthreads();
 
     // A fragment of (tile, half): the 4-float group `half`, swizzled like the writes
     const int a_tile = 32 * mi + lx;
     const float *a_lane = V + a_tile * PSV + ((half ^ ((a_tile >> 3) & 1)) * 4);
-    const float *b_lane0 = U + nj * 256 + lane * 4;
     // One wavefront per SIMD: nothing else hides this wave's non-MFMA instructions, and issue is in order -- so they are
     // dealt out BETWEEN the MFMAs (each keeps the matrix pipe busy for 64 cycles).  Positions are taken in pairs so that
     // consecutive MFMAs alternate between two accumulators; the 8 gaps of a pair carry
-    //   0, 1: the A / B fragment reads of the next pair          2, 4: LDS traffic of the next chunk's input transform
-    //   3, 5: its arithmetic (pairs 0, 1: more prefetch pieces)   6, 7: vector-memory prefetch pieces (patch c + 2 first:
-    //                                                                   it comes from HBM; then slab c + 1)
-    // The chunk's ONE barrier sits between its pairs 6 and 7: by then this wave has written its share of V[(c+1) & 1], stored
-    // the patch of chunk c + 2 and loaded the operands of pair 7, so the last pair's 8 MFMAs run while the barrier releases
-    // and the first fragments of chunk c + 1 arrive -- the matrix pipe does not drain at the chunk boundary.
-    f32x4 a0[2], b0[2], a1[2], b1[2];
+    //   1, 2: the A fragment reads of the next pair            3, 5: LDS traffic of the next chunk's input transform
+    //   4, 6: its arithmetic / the patch prefetch of chunk c + 2 (pairs 0, 1) / its store to LDS (pair 6)
+    //   7, 8: the B operands of the SAME positions for chunk c + 1 -- each register quad is reloaded right after its last
+    //         MFMA of this chunk was issued, a whole chunk (> 4000 cycles) before its next use
+    // The chunk's ONE barrier sits between its pairs 6 and 7: by then this wave has written its share of V[(c+1) & 1] and
+    // stored the patch of chunk c + 2, so the last pair's 8 MFMAs run while the barrier releases and the first fragments of
+    // chunk c + 1 arrive -- the matrix pipe does not drain at the chunk boundary.
+    f32x4 a0[2], a1[2];
     a0[0] = *reinterpret_cast<const f32x4 *>(a_lane);
-    b0[0] = *reinterpret_cast<const f32x4 *>(b_lane0);
     a1[0] = *reinterpret_cast<const f32x4 *>(a_lane + 64 * PSV);
-    b1[0] = *reinterpret_cast<const f32x4 *>(b_lane0 + 512);
     for (int cc = 0; cc < n_cc; ++cc) {
         const bool more = cc + 1 < n_cc, more2 = cc + 2 < n_cc;
+        const int cc_b = more ? cc + 1 : cc, cc_p = more2 ? cc + 2 : cc;   // what the (unconditional) prefetches ask for
         const float *a_cur = a_lane + (cc & 1) * V_FLOATS;
         const float *a_nxt = a_lane + ((cc + 1) & 1) * V_FLOATS;
         float *v_next = V + ((cc + 1) & 1) * V_FLOATS;
-        const float *b_lane = b_lane0 + (cc & 1) * U_FLOATS;
-        const float *b_nxt = b_lane0 + ((cc + 1) & 1) * U_FLOATS;
-        auto vmem_piece = [&](int k) {   // k = 0 .. NIT + N_DMA - 1
-            if (k < NIT) {
-                if (more2) fetch_patch_piece(cc + 2, k);
-            } else if (k < NIT + N_DMA) {
-                if (more) fetch_u_piece(cc + 1, k - NIT);
-            }
-        };
 #define L3C_WINO_MFMA(Q, T, A, B)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], acc[Q], 0, 0, 0);                 \
@@ -235,29 +223,20 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int pp = 0; pp < 8; ++pp) {
             const int q = 2 * pp, cur = pp & 1, nxt = cur ^ 1;
-            const f32x4 A0 = a0[cur], B0 = b0[cur], A1 = a1[cur], B1 = b1[cur];
+            const f32x4 A0 = a0[cur], A1 = a1[cur], B0 = bq[q], B1 = bq[q + 1];
             if (pp == 7) {
-                // everything chunk c + 1 needs from this wave is issued: patch c + 2 stored, V[(c+1) & 1] written, slab c + 1
-                // requested -- wait for the memory operations, then the barrier, then fetch the first fragments of chunk c + 1
-                __builtin_amdgcn_s_waitcnt(0x0F70);
+                // everything chunk c + 1 needs from this wave is issued: patch c + 2 stored, V[(c+1) & 1] written -- the
+                // barrier (LDS operations only: the B loads in flight stay in flight), then the first fragments of chunk c + 1
                 __syncthreads();
                 if (more) {
                     a0[nxt] = *reinterpret_cast<const f32x4 *>(a_nxt);
-                    b0[nxt] = *reinterpret_cast<const f32x4 *>(b_nxt);
                     a1[nxt] = *reinterpret_cast<const f32x4 *>(a_nxt + 64 * PSV);
-                    b1[nxt] = *reinterpret_cast<const f32x4 *>(b_nxt + 512);
                 }
             }
             L3C_WINO_MFMA(q, 0, A0, B0)
-            if (pp < 7) {
-                a0[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 2) * 64 * PSV);
-                b0[nxt] = *reinterpret_cast<const f32x4 *>(b_lane + (q + 2) * 512);
-            }
+            if (pp < 7) a0[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 2) * 64 * PSV);
             L3C_WINO_MFMA(q + 1, 0, A1, B1)
-            if (pp < 7) {
-                a1[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 3) * 64 * PSV);
-                b1[nxt] = *reinterpret_cast<const f32x4 *>(b_lane + (q + 3) * 512);
-            }
+            if (pp < 7) a1[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 3) * 64 * PSV);
             L3C_WINO_MFMA(q, 1, A0, B0)
             if (more) {
                 if (pp < 2) transform_load(cc + 1, 2 * pp);
@@ -265,7 +244,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 if (pp == 6) transform_write(v_next, 2);
             }
             L3C_WINO_MFMA(q + 1, 1, A1, B1)
-            if (pp < 2) vmem_piece(4 * pp);
+            if (pp == 0) fetch_patch_piece(cc_p, 0);
+            if (pp == 1) fetch_patch_piece(cc_p, 2);
+            if (pp == 6 && more2) store_patch(cc + 2);   // raw[c & 1]: read by the transform of chunk c during loop c - 1
             if (more) {
                 if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2));
                 if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4));
@@ -277,18 +258,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 if (pp == 6) transform_write(v_next, 3);
             }
             L3C_WINO_MFMA(q + 1, 2, A1, B1)
-            if (pp < 2) vmem_piece(4 * pp + 1);
+            if (pp == 0) fetch_patch_piece(cc_p, 1);
             if (more) {
                 if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2) + 1);
                 if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4) + 1);
             }
             L3C_WINO_MFMA(q, 3, A0, B0)
-            if (pp < 2) vmem_piece(4 * pp + 2);
-            else if (pp < 4) vmem_piece(8 + 2 * (pp - 2));
-            if (pp == 5 && more2) store_patch(cc + 2);   // raw[c & 1]: read by the transform of chunk c during loop c - 1
+            fetch_b(cc_b, q);
             L3C_WINO_MFMA(q + 1, 3, A1, B1)
-            if (pp < 2) vmem_piece(4 * pp + 3);
-            else if (pp < 4) vmem_piece(8 + 2 * (pp - 2) + 1);
+            fetch_b(cc_b, q + 1);
         }
 #undef L3C_WINO_MFMA
     }
