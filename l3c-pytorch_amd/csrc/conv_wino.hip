@@ -56,6 +56,8 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// RELU / RES / SHUFFLE: the epilogue variant, compile-time (no per-element selects).
+template <bool RELU, bool RES, bool SHUFFLE>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *raw = lds;                            // two buffers: patch of chunk k in raw[k & 1]
@@ -275,8 +277,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
     const int co = chunk_o * 64 + nj * 32 + lx;
     if (co >= p.Cout) return;
     const float bias = p.bias[co];
-    const bool relu = p.epilogue & L3C_EPI_RELU;
-    const bool shuffle = p.epilogue & L3C_EPI_PIXEL_SHUFFLE;
     const bool interior = py + dil * (sy0 + WT_H - 1) < p.H && px + dil * (sx0 + WT_W - 1) < p.W;
     auto y_of = [&](int r, float (&y)[2][2]) {
         float t0[4], t1[4];
@@ -290,24 +290,36 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
         y[1][0] = (t1[0] + t1[1]) + t1[2];
         y[1][1] = (t1[1] - t1[2]) - t1[3];
     };
-    if (interior && !shuffle) {
-        // tile (ty, tx) of this wave: ty = 2 mi + (r >> 3), tx = (r & 3) + 8 ((r >> 2) & 1) + 4 half -- all offsets are
-        // compile-time multiples of the row / pixel strides on top of one per-lane base
-        const int oyb = py + dil * (sy0 + 4 * mi), oxb = px + dil * (sx0 + 8 * half);
-        const int64_t row = (int64_t)dil * p.W * p.out_cstride, col = (int64_t)dil * p.out_cstride;
-        float *obase = p.out + (((size_t)b * p.H + oyb) * p.W + oxb) * p.out_cstride + p.out_coff + co;
-        const int64_t rrow = (int64_t)dil * p.W * p.res_cstride, rcol = (int64_t)dil * p.res_cstride;
-        const float *rbase = p.res ? p.res + (((size_t)b * p.H + oyb) * p.W + oxb) * p.res_cstride + p.res_coff + co : nullptr;
+    if (interior) {
+        // tile (ty, tx) of this wave: ty = 2 mi + (r >> 3), tx = (r & 3) + 8 ((r >> 2) & 1) + 4 half.  Buffer addressing:
+        // descriptor at the block's first output pixel (uniform), ONE per-lane byte offset, and a scalar offset per
+        // (row, pixel) -- no vector address arithmetic.  Pixel shuffle (dil = 1): conv pixel (oy, ox), channel co -> pixel
+        // (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2 of a 2H x 2W image, i.e. the same walk with doubled strides
+        // and the sub-pixel folded into the lane offset.
+        constexpr int S = SHUFFLE ? 2 : 1;
+        const int64_t col_b = (int64_t)S * dil * p.out_cstride * 4, row_b = (int64_t)S * dil * (S * p.W) * p.out_cstride * 4;
+        float *o_blk = p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * (px + dil * sx0)) * p.out_cstride +
+                       p.out_coff + (SHUFFLE ? chunk_o * 16 : chunk_o * 64);
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o_blk, 0, 0x7fffffff, 0x00020000);
+        const int cw = nj * 32 + lx;   // channel inside the 64-channel chunk
+        const int o_lane = (int)(4 * mi * row_b + 8 * half * col_b) +
+                           (SHUFFLE ? ((((cw >> 1) & 1) * (2 * p.W) + (cw & 1)) * p.out_cstride + (cw >> 2)) * 4 : cw * 4);
         // all 64 residual values of the lane first (one round trip instead of 64), then transform + store
         float resv[16][2][2];
-        if (rbase) {
+        if constexpr (RES) {
+            const int64_t rrow_b = (int64_t)dil * p.W * p.res_cstride * 4, rcol_b = (int64_t)dil * p.res_cstride * 4;
+            const float *r_blk = p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px + dil * sx0) * p.res_cstride + p.res_coff + chunk_o * 64;
+            const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(r_blk), 0, 0x7fffffff, 0x00020000);
+            const int r_lane = (int)(4 * mi * rrow_b + 8 * half * rcol_b) + cw * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ty2 = 2 * (r >> 3), tx2 = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) resv[r][dy][dx] = rbase[(ty2 + dy) * rrow + (tx2 + dx) * rcol];
+                    for (int dx = 0; dx < 2; ++dx)
+                        resv[r][dy][dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            r_rsrc, r_lane, (int)((ty2 + dy) * rrow_b + (tx2 + dx) * rcol_b), 0));
             }
         }
 #pragma unroll
@@ -320,13 +332,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
                     float v = y[dy][dx] + bias;
-                    if (relu) v = fmaxf(v, 0.0f);
-                    if (rbase) v = v + resv[r][dy][dx];
-                    obase[(ty2 + dy) * row + (tx2 + dx) * col] = v;
+                    if constexpr (RELU) v = fmaxf(v, 0.0f);
+                    if constexpr (RES) v = v + resv[r][dy][dx];
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, o_lane,
+                                                          (int)((ty2 + dy) * row_b + (tx2 + dx) * col_b), 0);
                 }
+            if (r & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles at a time (keeps the register demand flat)
         }
         return;
     }
+    // tiles that stick out of the image: per-element bounds checks and addresses
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int tl = (r & 3) + 8 * (r >> 2) + 4 * half;       // tile inside this wave's 32
@@ -340,9 +355,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
                 const int oy = py + dil * (sy0 + 2 * ty + dy), ox = px + dil * (sx0 + 2 * tx + dx);
                 if (oy >= p.H || ox >= p.W) continue;
                 float v = y[dy][dx] + bias;
-                if (relu) v = fmaxf(v, 0.0f);
-                if (p.res) v = v + p.res[(((size_t)b * p.H + oy) * p.W + ox) * p.res_cstride + p.res_coff + co];
-                if (shuffle) {
+                if constexpr (RELU) v = fmaxf(v, 0.0f);
+                if constexpr (RES) v = v + p.res[(((size_t)b * p.H + oy) * p.W + ox) * p.res_cstride + p.res_coff + co];
+                if constexpr (SHUFFLE) {
                     const size_t oyy = 2 * oy + ((co >> 1) & 1), oxx = 2 * ox + (co & 1);
                     p.out[(((size_t)b * 2 * p.H + oyy) * 2 * p.W + oxx) * p.out_cstride + p.out_coff + (co >> 2)] = v;
                 } else {
@@ -428,15 +443,22 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     const int64_t total = (int64_t)p.tiles_x * p.tiles_y * p.dil * p.dil * p.n_chunks_o * p.B;
     L3C_REQUIRE(total < (1ll << 31), "grid too large");
     p.total_blocks = (int)total;
-    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
-        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_wino_kernel),
+    typedef void (*kernel_t)(const WinoParams);
+    static const kernel_t variants[5] = {conv_wino_kernel<false, false, false>, conv_wino_kernel<true, false, false>,
+                                         conv_wino_kernel<false, true, false>, conv_wino_kernel<true, true, false>,
+                                         conv_wino_kernel<false, false, true>};
+    static bool attr_set[5] = {false, false, false, false, false};   // > 64 KB of dynamic LDS needs the opt-in
+    const bool relu = d->epilogue & L3C_EPI_RELU, res = d->epilogue & L3C_EPI_RESIDUAL, shuffle = d->epilogue & L3C_EPI_PIXEL_SHUFFLE;
+    L3C_REQUIRE(!(shuffle && relu), "pixel shuffle + ReLU not provided");
+    const int v = shuffle ? 4 : (relu ? 1 : 0) + (res ? 2 : 0);
+    if (!attr_set[v]) {
+        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(variants[v]),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES),
                                       "hipFuncSetAttribute");
         if (rc != L3C_OK) return rc;
-        attr_set = true;
+        attr_set[v] = true;
     }
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)total), dim3(256), WINO_LDS_BYTES, l3c::as_stream(stream), p);
+    hipLaunchKernelGGL(variants[v], dim3((unsigned)total), dim3(256), WINO_LDS_BYTES, l3c::as_stream(stream), p);
     return l3c::check_launch("conv_wino_kernel");
 }
 }

@@ -11,6 +11,8 @@ from l3c_pytorch_amd import ops, _lib  # noqa: E402
 from l3c_pytorch_amd._lib import call, ptr, stream  # noqa: E402
 
 ap = argparse.ArgumentParser()
+ap.add_argument('--res', action='store_true', help='time with the residual epilogue')
+ap.add_argument('--no-check', action='store_true')
 for k, v in dict(cin=64, cout=64, B=32, H=256, W=384, iters=10).items():
     ap.add_argument('--' + k, type=int, default=v)
 a = ap.parse_args()
@@ -40,7 +42,7 @@ def pack(w):
     return p
 
 
-for (B, H, W, Cout, relu, res, shuffle) in [(2, 16, 32, 64, False, False, False), (1, 9, 33, 64, True, False, False),
+for (B, H, W, Cout, relu, res, shuffle) in [] if a.no_check else [(2, 16, 32, 64, False, False, False), (1, 9, 33, 64, True, False, False),
                                             (3, 50, 70, 64, False, True, False), (2, 24, 40, 256, False, False, True),
                                             (1, 64, 96, 120, True, False, False)]:
     w = torch.randn(Cout, 64, 3, 3, generator=g) / 24
@@ -69,7 +71,8 @@ layer = ops.PackedConv(w, b)
 wp = pack(w)
 x = torch.randn(a.B, a.H, a.W, a.cin, generator=g).cuda()
 bc = b.cuda()
-for name, fn in [('mfma', lambda: ops.conv(x, layer, relu=True)), ('wino', lambda: wino(x, wp, bc, a.cout, relu=True))]:
+rt = torch.randn(a.B, a.H, a.W, a.cout, generator=g).cuda() if a.res else None
+for name, fn in [('mfma', lambda: ops.conv(x, layer, relu=True)), ('wino', lambda: wino(x, wp, bc, a.cout, relu=True, residual=rt))]:
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
