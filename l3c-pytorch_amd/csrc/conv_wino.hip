@@ -6,20 +6,27 @@
 // of the transformed tile, a plain GEMM  M[xi,nu] (tiles x Cout) = V[xi,nu] (tiles x Cin) * U[xi,nu] (Cin x Cout)  -- that part
 // runs on v_mfma_f32_32x32x2_f32; the transforms are a few dozen additions per tile and channel.
 //
-//   * block = 256 threads = 4 wavefronts (one per SIMD) on an 8 x 32 output tile = 4 x 16 = 64 Winograd tiles, 64 output
-//     channels; wavefront w owns 32 tiles (two tile rows) x 32 output channels for ALL 16 positions: 16 accumulator
-//     fragments = 256 registers (the AccVGPR half of the unified file), so the output transform is register-local --
-//     D register r of every fragment belongs to the same (tile, channel);
-//   * input channels in chunks of 8: the raw 10 x 34 patch is register-prefetched two chunks ahead, written to LDS one
-//     chunk ahead, and transformed by all 256 threads (thread = tile x channel pair: 16 ds_read_b64, 32 packed additions,
-//     16 ds_write_b64, bank-conflict-free) into the other V[16][64 tiles][8] buffer WHILE the MFMAs of the current chunk run
-//     -- the slices of the transform are interleaved into the MFMA loop;
-//   * the pre-transformed weights U (l3c_conv_wino_pack_weights: 16/9 of the 3x3 weights, MFMA fragment order) stream through
-//     a double-buffered LDS slab by LDS-DMA, one chunk ahead;
-//   * per position one ds_read_b128 of V and one of U feed four MFMAs (the k-ordering trick of conv_mfma.hip).
+//   * block = 256 threads = 4 wavefronts on a 4 x 32 output tile = 2 x 16 = 32 Winograd tiles, 64 output channels.
+//     Wavefront (nj, ph) owns 32 tiles x 32 output channels (nj) for the EIGHT positions of two columns nu = 2 ph, 2 ph + 1 of
+//     the transformed tile: 8 accumulator fragments = 128 registers.  A wavefront therefore needs at most 256 registers and a
+//     block 51 KB of LDS: TWO blocks share a CU (two wavefronts per SIMD), and while one block is in its prologue, at its
+//     chunk barrier or in its output transform, the matrix pipe runs the other one's MFMAs -- the hardware interleaves
+//     what a single 512-register wavefront per SIMD could only approximate by hand;
+//   * the output transform is linear, so each wavefront transforms ITS two columns (A^T M_ph A_ph) and the two halves of a
+//     (tile, channel) are added through LDS: wavefront ph finishes tile row ph, 8 x 16-byte LDS writes + reads per lane;
+//   * input channels in chunks of 8: the raw 6 x 34 patch of chunk k is fetched into registers during chunk k - 3, written to
+//     LDS during k - 2, transformed during k - 1 by all 256 threads (thread = tile x channel pair x output-row pair: 12
+//     ds_read_b64, 16 packed additions, 8 ds_write_b64, bank-conflict-free) into the other V[16][32 tiles][8] buffer WHILE the
+//     MFMAs of the current chunk run -- the slices of the transform are dealt out between the MFMAs;
+//   * the pre-transformed weights U (l3c_conv_wino_pack_weights: 16/9 of the 3x3 weights, MFMA fragment order) never touch
+//     LDS: position q of a chunk is ONE coalesced 16-byte buffer load per lane straight into the B operand registers, issued
+//     a whole chunk ahead (they come from L2: 256 KB per 64 output channels, shared by every block);
+//   * per position one ds_read_b128 of V and one operand quad of U feed four MFMAs (the k-ordering trick of conv_mfma.hip).
 // A dilated conv is the dense conv on each of the dil x dil interleaved sub-grids of the image: same kernel, strided indexing.
 // fp32 throughout; the result differs from the direct convolution by rounding only (transform coefficients are 1, 1/2).
 #include "l3c_common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -36,19 +43,23 @@ struct WinoParams {
     int in_cstride, in_coff, res_cstride, res_coff, out_cstride, out_coff;
     int B, H, W, Cin, Cout;
     int dil;          // 1, 2 or 4: the output grid splits into dil x dil interleaved sub-grids, each an ordinary 3x3 conv
+    int dil_log2;
     int epilogue;
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
 };
 
-constexpr int WT_H = 8, WT_W = 32;               // output tile of a block
+constexpr int WT_H = 4, WT_W = 32;               // output tile of a block: 2 x 16 Winograd tiles
 constexpr int WP_H = WT_H + 2, WP_W = WT_W + 2;  // input patch
+constexpr int N_TILES = (WT_H / 2) * (WT_W / 2);
 constexpr int WCK = 8;                           // input channels per chunk
 constexpr int PSR = 12;                          // LDS stride of a raw patch pixel (floats)
 constexpr int PSV = 8;                           // LDS stride of a transformed tile (floats), its two 4-float groups swizzled
 constexpr int RAW_FLOATS = WP_H * WP_W * PSR;
-constexpr int V_FLOATS = 16 * 64 * PSV;          // one buffer (two: the next chunk is transformed during the MFMA loop)
+constexpr int V_FLOATS = 16 * N_TILES * PSV;     // one buffer (two: the next chunk is transformed during the MFMA loop)
 constexpr int U_FLOATS = 16 * 2 * 64 * 4;        // packed weights of one input chunk x one 64-channel output chunk
-constexpr int WINO_LDS_BYTES = (2 * RAW_FLOATS + 2 * V_FLOATS) * 4;   // 98 176 bytes
+constexpr int X_FLOATS = 32 * 64;                // output-transform exchange: 32 partial sums per lane of a wavefront
+constexpr int WINO_LDS_BYTES = (2 * RAW_FLOATS + 2 * V_FLOATS) * 4;   // 52 352 bytes: two blocks per CU
+static_assert(4 * X_FLOATS <= 2 * V_FLOATS, "the exchange buffer aliases the V buffers");
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
     const int q = total >> 3, r = total & 7;
@@ -58,213 +69,207 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
 
 // RELU / RES / SHUFFLE: the epilogue variant, compile-time (no per-element selects).
 template <bool RELU, bool RES, bool SHUFFLE>
-__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
+__global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *raw = lds;                            // two buffers: patch of chunk k in raw[k & 1]
-    float *V = lds + 2 * RAW_FLOATS;             // two buffers
+    float *V = lds + 2 * RAW_FLOATS;             // two buffers: transformed tiles of chunk k in V[k & 1]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and the compiler knows it
     const int half = lane >> 5, lx = lane & 31;
-    const int mi = wave & 1, nj = wave >> 1;
+    const int nj = wave & 1, ph = wave >> 1;     // output-channel half; column pair nu = 2 ph, 2 ph + 1 of the transformed tile
     const int n_cc = p.Cin / WCK;
 
-    int w = xcd_remap_w(blockIdx.x, p.total_blocks);
-    const int tiles = p.tiles_x * p.tiles_y;
-    const int tile = w % tiles;
+    unsigned w = (unsigned)xcd_remap_w(blockIdx.x, p.total_blocks);
+    const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
+    const unsigned tile = w % tiles;
     w /= tiles;
-    const int phase = w % (p.dil * p.dil);   // which of the dil x dil sub-grids (dilated conv = dense conv on each of them)
-    w /= p.dil * p.dil;
-    const int chunk_o = w % p.n_chunks_o;
-    const int b = w / p.n_chunks_o;
-    const int dil = p.dil, py = phase / dil, px = phase % dil;
-    const int sy0 = (tile / p.tiles_x) * WT_H, sx0 = (tile % p.tiles_x) * WT_W;   // tile origin in sub-grid coordinates
+    const int dl = p.dil_log2, dil = 1 << dl;
+    const int phase = (int)(w & ((1u << (2 * dl)) - 1));   // which of the dil x dil sub-grids (dilated conv = dense conv on each)
+    w >>= 2 * dl;
+    const int chunk_o = p.n_chunks_o == 1 ? 0 : (int)(w % (unsigned)p.n_chunks_o);
+    const int b = p.n_chunks_o == 1 ? (int)w : (int)(w / (unsigned)p.n_chunks_o);
+    const int py = phase >> dl, px = phase & (dil - 1);
+    const int sy0 = (int)(tile / (unsigned)p.tiles_x) * WT_H, sx0 = (int)(tile % (unsigned)p.tiles_x) * WT_W;   // tile origin (sub-grid)
 
-    constexpr int NIT = (WP_H * WP_W * 2 + 255) / 256;
+    constexpr int N_PIECES = WP_H * WP_W * 2;    // 16-byte pieces of a patch (a pixel's 8 channels = 2 pieces)
+    constexpr int NIT = (N_PIECES + 255) / 256;
+    static_assert(NIT == 2, "the patch prefetch pieces are dealt out by hand below");
     f32x4 stage_regs[NIT];
-    // this thread's patch elements: offsets relative to the image / channel-chunk base, fixed for the whole block
-    int64_t patch_off[NIT];
-    bool patch_ok[NIT];
+    // this thread's patch elements: byte offsets relative to the image base, fixed for the whole block.  The image is one
+    // buffer descriptor: a piece outside it (zero padding) gets an offset beyond the buffer and reads as zero.
+    int patch_off[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int i = tid + it * 256;
         const int c4 = i & 1, pix = i >> 1;
         const int r = pix / WP_W, ci = pix % WP_W;
         const int iy = py + dil * (sy0 - 1 + r), ix = px + dil * (sx0 - 1 + ci);
-        patch_ok[it] = pix < WP_H * WP_W && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        patch_off[it] = patch_ok[it] ? ((int64_t)iy * p.W + ix) * p.in_cstride + c4 * 4 : 0;   // padding: any valid address
+        const bool ok = i < N_PIECES && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        patch_off[it] = ok ? ((iy * p.W + ix) * p.in_cstride + c4 * 4) * 4 : 0x7ffffff0;
     }
-    const float *in_b = p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff;
-    // B operands (transformed weights): the packed layout IS the MFMA fragment order, so position q of chunk cc is ONE
-    // coalesced 16-byte load per lane straight into the operand registers (uniform base + per-lane offset) -- no LDS staging.
-    // Buffer addressing: uniform descriptor + per-lane byte offset (fixed) + scalar offset -- no vector address arithmetic.
-    // Every load inside the chunk loop is UNCONDITIONAL (the last chunks re-request a slice they already have): a load
-    // behind a branch would make the compiler's count of outstanding loads imprecise and turn its waits into vmcnt(0).
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff), 0, p.H * p.W * p.in_cstride * 4, 0x00020000);
+    // B operands: uniform descriptor + fixed per-lane byte offset + scalar offset, no vector address arithmetic.  Every load
+    // inside the chunk loop is UNCONDITIONAL (the last chunks re-request a slice they already have): a load behind a branch
+    // would make the compiler's count of outstanding loads imprecise and turn its waits into vmcnt(0).
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u + (size_t)chunk_o * n_cc * U_FLOATS), 0,
                                                           n_cc * U_FLOATS * 4, 0x00020000);
-    const int u_lane = (nj * 256 + lane * 4) * 4;
-    f32x4 bq[16];
-    auto fetch_b = [&](int cc, int q) {
-        bq[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (cc * U_FLOATS + q * 512) * 4, 0));
+    const int u_lane = (ph * 2 * 512 + nj * 256 + lane * 4) * 4;   // the wavefront's first position is 2 ph
+    f32x4 bq[8];   // operand a = 0..7 <-> position (a >> 1) * 4 + 2 ph + (a & 1)
+    auto fetch_b = [&](int cc, int a) {
+        bq[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              u_rsrc, u_lane, (cc * U_FLOATS + ((a >> 1) * 4 + (a & 1)) * 512) * 4, 0));
     };
-    auto fetch_patch_piece = [&](int cc, int it) {   // zero padding is applied by store_patch
-        stage_regs[it] = *reinterpret_cast<const f32x4 *>(in_b + cc * WCK + patch_off[it]);
+    auto fetch_patch_piece = [&](int cc, int it) {
+        stage_regs[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], cc * WCK * 4, 0));
     };
     auto fetch_patch = [&](int cc) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) fetch_patch_piece(cc, it);
     };
-    static_assert(NIT == 3, "the patch prefetch pieces are dealt out by hand below");
-    auto store_patch = [&](int cc) {
-        float *dst = raw + (cc & 1) * RAW_FLOATS;
+    auto store_patch = [&](int par) {
+        float *dst = raw + par * RAW_FLOATS;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
             const int c4 = i & 1, pix = i >> 1;
-            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-            if (pix < WP_H * WP_W) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = patch_ok[it] ? stage_regs[it] : zero;
+            if (i < N_PIECES) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = stage_regs[it];
         }
     };
-    // Input transform B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]) of this thread's (tile, channel pair): wave w
-    // takes tile row w, lane = (tile column, channel pair) -- 8 tiles x 4 pairs per 32 lanes cover all 64 LDS banks on the
+    // Input transform B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]).  Wavefront w = (tile row t_ty, output-row pair
+    // t_h): lane = (tile column, channel pair) computes rows xi = 2 t_h, 2 t_h + 1 of its tile's transform -- these need the
+    // three input rows t_h .. t_h + 2 -- for both channels: 8 tiles x 4 pairs per 32 lanes cover all 64 LDS banks on the
     // reads (pixel stride 12 floats) and on the writes (tile stride 8 floats).  The two 4-float groups of a tile are swapped
     // for tiles 8..15 of a row (XOR swizzle), which makes the MFMA A-fragment reads (16 tiles x 16 B per pass) conflict-free.
-    const int t_tx = lane >> 2, t_cq = lane & 3, t_ty = wave;
+    const int t_tx = lane >> 2, t_cq = lane & 3, t_ty = wave & 1, t_h = wave >> 1;
+    // rows xi = 2 t_h, 2 t_h + 1 of B^T d as  e0 = x - z,  e1 = s y + z  with (x, y, z; s) = (d0, d1, d2; +1) for t_h = 0 and
+    // (d2, d3, d1; -1) for t_h = 1: ONE instruction stream for all four wavefronts, the difference is in the LDS addresses
     const float *t_src = raw + ((2 * t_ty) * WP_W + 2 * t_tx) * PSR + 2 * t_cq;
-    const int t_dst = (t_ty * 16 + t_tx) * PSV + (((t_cq >> 1) ^ (t_tx >> 3)) * 4) + (t_cq & 1) * 2;
-    f32x2 d[4][4];
-    auto transform_load = [&](int cc, int i) {
-        const float *src = t_src + (cc & 1) * RAW_FLOATS;
+    const int t_row[3] = {2 * t_h, 1 + 2 * t_h, 2 - t_h};
+    const float t_s = t_h ? -1.0f : 1.0f;
+    const int t_dst = (t_ty * 16 + t_tx) * PSV + (((t_cq >> 1) ^ (t_tx >> 3)) * 4) + (t_cq & 1) * 2 + (2 * t_h * 4) * N_TILES * PSV;
+    f32x2 d[3][4], e[2][4];
+    auto transform_load = [&](int par, int i) {   // i = 0, 1, 2: x, y, z
+        const float *src = t_src + par * RAW_FLOATS + t_row[i] * WP_W * PSR;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2 *>(src + (i * WP_W + j) * PSR);
+        for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2 *>(src + j * PSR);
     };
-    auto transform_rows_col = [&](int j) {   // column j of d <- B^T d
-        const f32x2 b0 = d[0][j] - d[2][j], b1 = d[1][j] + d[2][j], b2 = d[2][j] - d[1][j], b3 = d[1][j] - d[3][j];
-        d[0][j] = b0;
-        d[1][j] = b1;
-        d[2][j] = b2;
-        d[3][j] = b3;
-    };
-    auto transform_rows = [&]() {   // d <- B^T d  (in place, column by column)
+    auto transform_rows = [&](int k) {   // e[k] = row 2 t_h + k of B^T d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x2 b0 = d[0][j] - d[2][j], b1 = d[1][j] + d[2][j], b2 = d[2][j] - d[1][j], b3 = d[1][j] - d[3][j];
-            d[0][j] = b0;
-            d[1][j] = b1;
-            d[2][j] = b2;
-            d[3][j] = b3;
+            if (k == 0) {
+                e[0][j] = d[0][j] - d[2][j];
+            } else {   // s = +-1: the product is exact
+                e[1][j][0] = __builtin_fmaf(t_s, d[1][j][0], d[2][j][0]);
+                e[1][j][1] = __builtin_fmaf(t_s, d[1][j][1], d[2][j][1]);
+            }
         }
     };
-    auto transform_cols_row = [&](int i) {   // row i of d <- d B
-        const f32x2 c0 = d[i][0] - d[i][2], c1 = d[i][1] + d[i][2], c2 = d[i][2] - d[i][1], c3 = d[i][1] - d[i][3];
-        d[i][0] = c0;
-        d[i][1] = c1;
-        d[i][2] = c2;
-        d[i][3] = c3;
+    auto transform_cols = [&](int k) {   // e[k] <- e[k] B
+        const f32x2 c0 = e[k][0] - e[k][2], c1 = e[k][1] + e[k][2], c2 = e[k][2] - e[k][1], c3 = e[k][1] - e[k][3];
+        e[k][0] = c0;
+        e[k][1] = c1;
+        e[k][2] = c2;
+        e[k][3] = c3;
     };
-    auto transform_write = [&](float *Vdst, int i) {   // finished row i -> positions 4 i .. 4 i + 3
-        float *dst = Vdst + t_dst + (i * 4) * 64 * PSV;
+    auto transform_write = [&](float *Vdst, int k) {   // finished row 2 t_h + k -> positions 4 (2 t_h + k) .. + 3
+        float *dst = Vdst + t_dst + (k * 4) * N_TILES * PSV;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(dst + j * 64 * PSV) = d[i][j];
-    };
-    auto transform_store = [&](float *Vdst, int i) {   // row i of (B^T d) B -> positions 4 i .. 4 i + 3
-        float *dst = Vdst + t_dst + (i * 4) * 64 * PSV;
-        *reinterpret_cast<f32x2 *>(dst + 0 * 64 * PSV) = d[i][0] - d[i][2];
-        *reinterpret_cast<f32x2 *>(dst + 1 * 64 * PSV) = d[i][1] + d[i][2];
-        *reinterpret_cast<f32x2 *>(dst + 2 * 64 * PSV) = d[i][2] - d[i][1];
-        *reinterpret_cast<f32x2 *>(dst + 3 * 64 * PSV) = d[i][1] - d[i][3];
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(dst + j * N_TILES * PSV) = e[k][j];
     };
 
-    f32x16 acc[16];
+    f32x16 acc[8];
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
 
-    // Prologue.  Invariants at the start of the MFMA loop of chunk c:  V[c & 1] and slab c & 1 complete and visible; the operand
-    // fragments of its first position pair loaded; raw[(c+1) & 1] = patch of chunk c + 1, visible; the staging registers free.
+    // Prologue.  Invariants at the start of the MFMA loop of chunk c:  V[c & 1] complete and visible; bq = its B operands (in
+    // flight); a0[0], a1[0] = the A fragments of its first position pair; raw[(c+1) & 1] = patch of chunk c + 1, visible; the
+    // staging registers = patch of chunk c + 2 (in flight).  Chunk indices past the end are clamped: the loads stay
+    // unconditional, their data is never used.
+    auto clamp_cc = [&](int cc) { return cc < n_cc ? cc : n_cc - 1; };
     fetch_patch(0);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) fetch_b(0, q);
     store_patch(0);
-    if (n_cc > 1) fetch_patch(1);
+    fetch_patch(clamp_cc(1));
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 4; ++i) transform_load(0, i);
-    transform_rows();
+    for (int i = 0; i < 3; ++i) transform_load(0, i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) transform_store(V, i);
-    if (n_cc > 1) store_patch(1);
+    for (int k = 0; k < 2; ++k) {
+        transform_rows(k);
+        transform_cols(k);
+        transform_write(V, k);
+    }
+    store_patch(1);
+    fetch_patch(clamp_cc(2));
+    // the B operands AFTER the last patch fetch: the loads then are outstanding in the same order as at the top of every later
+    // chunk (patch, then B), and the loop's waits -- which the compiler derives for the worst path -- fit the steady state
+#pragma unroll
+    for (int a = 0; a < 8; ++a) fetch_b(0, a);
     __syncthreads();
 
-    // A fragment of (tile, half): the 4-float group `half`, swizzled like the writes
-    const int a_tile = 32 * mi + lx;
-    const float *a_lane = V + a_tile * PSV + ((half ^ ((a_tile >> 3) & 1)) * 4);
-    // One wavefront per SIMD: nothing else hides this wave's non-MFMA instructions, and issue is in order -- so they are
-    // dealt out BETWEEN the MFMAs (each keeps the matrix pipe busy for 64 cycles).  Positions are taken in pairs so that
-    // consecutive MFMAs alternate between two accumulators; the 8 gaps of a pair carry
-    //   1, 2: the A fragment reads of the next pair            3, 5: LDS traffic of the next chunk's input transform
-    //   4, 6: its arithmetic / the patch prefetch of chunk c + 2 (pairs 0, 1) / its store to LDS (pair 6)
+    // A fragment of (tile, half): the 4-float group `half`, swizzled like the writes; position stride N_TILES * PSV
+    const float *a_lane = V + lx * PSV + ((half ^ ((lx >> 3) & 1)) * 4) + (2 * ph) * N_TILES * PSV;
+    auto a_pos = [&](int a) { return ((a >> 1) * 4 + (a & 1)) * N_TILES * PSV; };   // operand a of this wavefront
+    // Issue is in order: the non-MFMA instructions are dealt out BETWEEN the MFMAs (each keeps the matrix pipe busy for 64
+    // cycles; whatever does not fit is covered by the co-resident block's wavefront on the same SIMD).  Positions are taken
+    // in pairs so that consecutive MFMAs alternate between two accumulators; the 8 gaps of a pair carry
+    //   1, 2: the A fragment reads of the next pair
+    //   3 .. 6: pair 0: store patch c + 2 (fetched during chunk c - 1), fetch patch c + 3, first LDS reads of the transform of
+    //           chunk c + 1; pair 1: its remaining reads and the row stage; pair 2: the column stage and the writes to V
     //   7, 8: the B operands of the SAME positions for chunk c + 1 -- each register quad is reloaded right after its last
-    //         MFMA of this chunk was issued, a whole chunk (> 4000 cycles) before its next use
-    // The chunk's ONE barrier sits between its pairs 6 and 7: by then this wave has written its share of V[(c+1) & 1] and
+    //         MFMA of this chunk was issued, a whole chunk ahead of its next use
+    // The chunk's ONE barrier sits between its pairs 2 and 3: by then this wave has written its share of V[(c+1) & 1] and
     // stored the patch of chunk c + 2, so the last pair's 8 MFMAs run while the barrier releases and the first fragments of
-    // chunk c + 1 arrive -- the matrix pipe does not drain at the chunk boundary.
+    // chunk c + 1 arrive.
     f32x4 a0[2], a1[2];
-    a0[0] = *reinterpret_cast<const f32x4 *>(a_lane);
-    a1[0] = *reinterpret_cast<const f32x4 *>(a_lane + 64 * PSV);
+    a0[0] = *reinterpret_cast<const f32x4 *>(a_lane + a_pos(0));
+    a1[0] = *reinterpret_cast<const f32x4 *>(a_lane + a_pos(1));
     for (int cc = 0; cc < n_cc; ++cc) {
-        const bool more = cc + 1 < n_cc, more2 = cc + 2 < n_cc;
-        const int cc_b = more ? cc + 1 : cc, cc_p = more2 ? cc + 2 : cc;   // what the (unconditional) prefetches ask for
-        const float *a_cur = a_lane + (cc & 1) * V_FLOATS;
-        const float *a_nxt = a_lane + ((cc + 1) & 1) * V_FLOATS;
-        float *v_next = V + ((cc + 1) & 1) * V_FLOATS;
+        // No branches on "is there another chunk": the last chunks fetch, store and transform (clamped) data that nobody
+        // reads -- cheaper than seventeen uniform branches per chunk, and it keeps the compiler's load counts exact.
+        const int cc_b = clamp_cc(cc + 1), cc_p = clamp_cc(cc + 3);
+        const int par = cc & 1;
+        const float *a_cur = a_lane + par * V_FLOATS;
+        const float *a_nxt = a_lane + (par ^ 1) * V_FLOATS;
+        float *v_next = V + (par ^ 1) * V_FLOATS;
 #define L3C_WINO_MFMA(Q, T, A, B)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], acc[Q], 0, 0, 0);                 \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const int q = 2 * pp, cur = pp & 1, nxt = cur ^ 1;
-            const f32x4 A0 = a0[cur], A1 = a1[cur], B0 = bq[q], B1 = bq[q + 1];
-            if (pp == 7) {
+        for (int pp = 0; pp < 4; ++pp) {
+            const int q = 2 * pp, cb = pp & 1, nb = cb ^ 1;
+            const f32x4 A0 = a0[cb], A1 = a1[cb], B0 = bq[q], B1 = bq[q + 1];
+            if (pp == 3) {
                 // everything chunk c + 1 needs from this wave is issued: patch c + 2 stored, V[(c+1) & 1] written -- the
-                // barrier (LDS operations only: the B loads in flight stay in flight), then the first fragments of chunk c + 1
+                // barrier (LDS operations only: the loads in flight stay in flight), then the first fragments of chunk c + 1
                 __syncthreads();
-                if (more) {
-                    a0[nxt] = *reinterpret_cast<const f32x4 *>(a_nxt);
-                    a1[nxt] = *reinterpret_cast<const f32x4 *>(a_nxt + 64 * PSV);
-                }
+                a0[nb] = *reinterpret_cast<const f32x4 *>(a_nxt + a_pos(0));
+                a1[nb] = *reinterpret_cast<const f32x4 *>(a_nxt + a_pos(1));
             }
             L3C_WINO_MFMA(q, 0, A0, B0)
-            if (pp < 7) a0[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 2) * 64 * PSV);
+            if (pp < 3) a0[nb] = *reinterpret_cast<const f32x4 *>(a_cur + a_pos(q + 2));
             L3C_WINO_MFMA(q + 1, 0, A1, B1)
-            if (pp < 7) a1[nxt] = *reinterpret_cast<const f32x4 *>(a_cur + (q + 3) * 64 * PSV);
+            if (pp < 3) a1[nb] = *reinterpret_cast<const f32x4 *>(a_cur + a_pos(q + 3));
             L3C_WINO_MFMA(q, 1, A0, B0)
-            if (more) {
-                if (pp < 2) transform_load(cc + 1, 2 * pp);
-                if (pp == 5) transform_write(v_next, 0);
-                if (pp == 6) transform_write(v_next, 2);
-            }
+            if (pp == 0) store_patch(par);   // patch c + 2 -> raw[c & 1] (its previous patch was transformed during c - 1)
+            if (pp == 1) transform_load(par ^ 1, 1);
+            if (pp == 2) transform_cols(0);
             L3C_WINO_MFMA(q + 1, 1, A1, B1)
             if (pp == 0) fetch_patch_piece(cc_p, 0);
-            if (pp == 1) fetch_patch_piece(cc_p, 2);
-            if (pp == 6 && more2) store_patch(cc + 2);   // raw[c & 1]: read by the transform of chunk c during loop c - 1
-            if (more) {
-                if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2));
-                if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4));
-            }
+            if (pp == 1) transform_rows(0);
+            if (pp == 2) transform_write(v_next, 0);
             L3C_WINO_MFMA(q, 2, A0, B0)
-            if (more) {
-                if (pp < 2) transform_load(cc + 1, 2 * pp + 1);
-                if (pp == 5) transform_write(v_next, 1);
-                if (pp == 6) transform_write(v_next, 3);
-            }
+            if (pp == 0) transform_load(par ^ 1, 0);
+            if (pp == 1) transform_rows(1);
+            if (pp == 2) transform_cols(1);
             L3C_WINO_MFMA(q + 1, 2, A1, B1)
             if (pp == 0) fetch_patch_piece(cc_p, 1);
-            if (more) {
-                if (pp == 2 || pp == 3) transform_rows_col(2 * (pp - 2) + 1);
-                if (pp == 4 || pp == 5) transform_cols_row(2 * (pp - 4) + 1);
-            }
+            if (pp == 0) transform_load(par ^ 1, 2);
+            if (pp == 2) transform_write(v_next, 1);
             L3C_WINO_MFMA(q, 3, A0, B0)
             fetch_b(cc_b, q);
             L3C_WINO_MFMA(q + 1, 3, A1, B1)
@@ -273,88 +278,117 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const WinoParams p) {
 #undef L3C_WINO_MFMA
     }
 
-    // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]), register-local, + bias / ReLU / residual / store ----
-    const int co = chunk_o * 64 + nj * 32 + lx;
-    if (co >= p.Cout) return;
-    const float bias = p.bias[co];
-    const bool interior = py + dil * (sy0 + WT_H - 1) < p.H && px + dil * (sx0 + WT_W - 1) < p.W;
-    auto y_of = [&](int r, float (&y)[2][2]) {
-        float t0[4], t1[4];
+    // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]).  This wavefront holds columns nu = 2 ph, 2 ph + 1 of M:
+    // with t_i[n] = sum_xi A^T[i][xi] M[xi][2 ph + n] its share of Y[i][j] is  sum_n t_i[n] A^T[j][2 ph + n]:
+    //   ph = 0:  P[i][0] = t_i[0] + t_i[1],  P[i][1] = t_i[1];        ph = 1:  P[i][0] = t_i[0],  P[i][1] = -t_i[0] - t_i[1].
+    // D register r of a fragment belongs to tile (ty, tx) = (r >> 3, (r & 3) + 8 ((r >> 2) & 1) + 4 half): wavefront ph keeps
+    // the partial sums of tile row ph, hands those of the other row to its partner (same nj, other ph) through LDS, adds the
+    // partner's, then bias / ReLU / residual / store.
+    const int cw = nj * 32 + lx;   // channel inside the 64-channel chunk
+    const int co = chunk_o * 64 + cw;
+    const bool co_ok = co < p.Cout;
+    const float bias = co_ok ? p.bias[co] : 0.0f;
+    float mine[8][2][2];
+    {
+        float *X = V + wave * X_FLOATS + lane * 4;   // after the last chunk's barrier nobody reads V any more
+        auto partials = [&](auto ph_c) __attribute__((always_inline)) {
+            constexpr int PH = decltype(ph_c)::value;
 #pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            t0[nu] = (acc[0 + nu][r] + acc[4 + nu][r]) + acc[8 + nu][r];
-            t1[nu] = (acc[4 + nu][r] - acc[8 + nu][r]) - acc[12 + nu][r];
+            for (int r = 0; r < 16; ++r) {
+                float t[2][2], P[2][2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    t[0][n] = (acc[0 + n][r] + acc[2 + n][r]) + acc[4 + n][r];
+                    t[1][n] = (acc[2 + n][r] - acc[4 + n][r]) - acc[6 + n][r];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    P[i][0] = PH == 0 ? t[i][0] + t[i][1] : t[i][0];
+                    P[i][1] = PH == 0 ? t[i][1] : (-t[i][0]) - t[i][1];
+                }
+                if ((r >> 3) == PH) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) mine[r & 7][i][j] = P[i][j];
+                } else {
+                    const f32x4 v = {P[0][0], P[0][1], P[1][0], P[1][1]};
+                    *reinterpret_cast<f32x4 *>(X + (r & 7) * 256) = v;
+                }
+            }
+        };
+        if (ph == 0) partials(std::integral_constant<int, 0>{});
+        else partials(std::integral_constant<int, 1>{});
+        __syncthreads();
+        const float *Xp = V + (wave ^ 2) * X_FLOATS + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(Xp + k * 256);
+            mine[k][0][0] += v[0];
+            mine[k][0][1] += v[1];
+            mine[k][1][0] += v[2];
+            mine[k][1][1] += v[3];
         }
-        y[0][0] = (t0[0] + t0[1]) + t0[2];
-        y[0][1] = (t0[1] - t0[2]) - t0[3];
-        y[1][0] = (t1[0] + t1[1]) + t1[2];
-        y[1][1] = (t1[1] - t1[2]) - t1[3];
-    };
+    }
+    // tile row ph of the block: outputs rows 2 ph, 2 ph + 1; tile k: tx = (k & 3) + 8 ((k >> 2) & 1) + 4 half
+    const bool interior = py + dil * (sy0 + WT_H - 1) < p.H && px + dil * (sx0 + WT_W - 1) < p.W;
     if (interior) {
-        // tile (ty, tx) of this wave: ty = 2 mi + (r >> 3), tx = (r & 3) + 8 ((r >> 2) & 1) + 4 half.  Buffer addressing:
-        // descriptor at the block's first output pixel (uniform), ONE per-lane byte offset, and a scalar offset per
-        // (row, pixel) -- no vector address arithmetic.  Pixel shuffle (dil = 1): conv pixel (oy, ox), channel co -> pixel
-        // (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2 of a 2H x 2W image, i.e. the same walk with doubled strides
-        // and the sub-pixel folded into the lane offset.
+        // Buffer addressing: descriptor at the block's first output pixel (uniform), ONE per-lane byte offset, and a scalar
+        // offset per (row, pixel) -- no vector address arithmetic.  Pixel shuffle (dil = 1): conv pixel (oy, ox), channel co
+        // -> pixel (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2 of a 2H x 2W image, i.e. the same walk with doubled
+        // strides and the sub-pixel folded into the lane offset.
         constexpr int S = SHUFFLE ? 2 : 1;
         const int64_t col_b = (int64_t)S * dil * p.out_cstride * 4, row_b = (int64_t)S * dil * (S * p.W) * p.out_cstride * 4;
         float *o_blk = p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * (px + dil * sx0)) * p.out_cstride +
                        p.out_coff + (SHUFFLE ? chunk_o * 16 : chunk_o * 64);
-        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o_blk, 0, 0x7fffffff, 0x00020000);
-        const int cw = nj * 32 + lx;   // channel inside the 64-channel chunk
-        const int o_lane = (int)(4 * mi * row_b + 8 * half * col_b) +
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o_blk, 0, co_ok ? 0x7fffffff : 0, 0x00020000);
+        const int o_lane = (int)(2 * ph * row_b + 8 * half * col_b) +
                            (SHUFFLE ? ((((cw >> 1) & 1) * (2 * p.W) + (cw & 1)) * p.out_cstride + (cw >> 2)) * 4 : cw * 4);
-        // all 64 residual values of the lane first (one round trip instead of 64), then transform + store
-        float resv[16][2][2];
-        if constexpr (RES) {
+        float resv[8][2][2];
+        if constexpr (RES) {   // all 32 residual values of the lane first (one round trip instead of 32)
             const int64_t rrow_b = (int64_t)dil * p.W * p.res_cstride * 4, rcol_b = (int64_t)dil * p.res_cstride * 4;
             const float *r_blk = p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px + dil * sx0) * p.res_cstride + p.res_coff + chunk_o * 64;
-            const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(r_blk), 0, 0x7fffffff, 0x00020000);
-            const int r_lane = (int)(4 * mi * rrow_b + 8 * half * rcol_b) + cw * 4;
+            const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(r_blk), 0, co_ok ? 0x7fffffff : 0, 0x00020000);
+            const int r_lane = (int)(2 * ph * rrow_b + 8 * half * rcol_b) + cw * 4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ty2 = 2 * (r >> 3), tx2 = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
+            for (int k = 0; k < 8; ++k) {
+                const int tx2 = 2 * ((k & 3) + 8 * ((k >> 2) & 1));
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx)
-                        resv[r][dy][dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            r_rsrc, r_lane, (int)((ty2 + dy) * rrow_b + (tx2 + dx) * rcol_b), 0));
+                        resv[k][dy][dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            r_rsrc, r_lane, (int)(dy * rrow_b + (tx2 + dx) * rcol_b), 0));
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float y[2][2];
-            y_of(r, y);
-            const int ty2 = 2 * (r >> 3), tx2 = 2 * ((r & 3) + 8 * ((r >> 2) & 1));
+        for (int k = 0; k < 8; ++k) {
+            const int tx2 = 2 * ((k & 3) + 8 * ((k >> 2) & 1));
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx) {
-                    float v = y[dy][dx] + bias;
+                    float v = mine[k][dy][dx] + bias;
                     if constexpr (RELU) v = fmaxf(v, 0.0f);
-                    if constexpr (RES) v = v + resv[r][dy][dx];
+                    if constexpr (RES) v = v + resv[k][dy][dx];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, o_lane,
-                                                          (int)((ty2 + dy) * row_b + (tx2 + dx) * col_b), 0);
+                                                          (int)(dy * row_b + (tx2 + dx) * col_b), 0);
                 }
-            if (r & 1) __builtin_amdgcn_sched_barrier(0);   // two tiles at a time (keeps the register demand flat)
         }
         return;
     }
     // tiles that stick out of the image: per-element bounds checks and addresses
+    if (!co_ok) return;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int tl = (r & 3) + 8 * (r >> 2) + 4 * half;       // tile inside this wave's 32
-        const int ty = 2 * mi + (tl >> 4), tx = tl & 15;
-        float y[2][2];
-        y_of(r, y);
+    for (int k = 0; k < 8; ++k) {
+        const int ty = ph, tx = (k & 3) + 8 * ((k >> 2) & 1) + 4 * half;
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 const int oy = py + dil * (sy0 + 2 * ty + dy), ox = px + dil * (sx0 + 2 * tx + dx);
                 if (oy >= p.H || ox >= p.W) continue;
-                float v = y[dy][dx] + bias;
+                float v = mine[k][dy][dx] + bias;
                 if constexpr (RELU) v = fmaxf(v, 0.0f);
                 if constexpr (RES) v = v + p.res[(((size_t)b * p.H + oy) * p.W + ox) * p.res_cstride + p.res_coff + co];
                 if constexpr (SHUFFLE) {
@@ -437,6 +471,7 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = d->Cin;  p.Cout = d->Cout;
     p.epilogue = d->epilogue;
     p.dil = d->dilation;
+    p.dil_log2 = d->dilation == 4 ? 2 : d->dilation == 2 ? 1 : 0;
     p.tiles_x = ((p.W + p.dil - 1) / p.dil + WT_W - 1) / WT_W;   // tiles of the (largest) sub-grid
     p.tiles_y = ((p.H + p.dil - 1) / p.dil + WT_H - 1) / WT_H;
     p.n_chunks_o = (p.Cout + 63) / 64;
