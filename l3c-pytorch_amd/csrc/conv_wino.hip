@@ -26,6 +26,7 @@
 // fp32 throughout; the result differs from the direct convolution by rounding only (transform coefficients are 1, 1/2).
 #include "l3c_common.h"
 
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -33,6 +34,21 @@ namespace {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// n / d for 0 <= n < 2^31 as a multiplication (Granlund-Montgomery: m = floor(2^(31+L) / d) + 1, L = ceil(log2 d))
+struct WinoDiv {
+    unsigned m, sh;   // d == 1: m = 0
+    __device__ __forceinline__ unsigned div(unsigned n) const { return m ? __umulhi(n, m) >> sh : n; }
+};
+static WinoDiv wino_div(unsigned d) {
+    WinoDiv r{0, 0};
+    if (d <= 1) return r;
+    unsigned L = 0;
+    while ((1ull << L) < d) ++L;
+    r.m = (unsigned)(((1ull << (31 + L)) / d) + 1);
+    r.sh = L - 1;
+    return r;
+}
 
 struct WinoParams {
     const float *in;
@@ -44,6 +60,10 @@ struct WinoParams {
     int B, H, W, Cin, Cout;
     int dil;          // 1, 2 or 4: the output grid splits into dil x dil interleaved sub-grids, each an ordinary 3x3 conv
     int dil_log2;
+    WinoDiv div_tiles, div_tiles_x, div_chunks;
+#ifdef L3C_WINO_TIMELINE
+    unsigned long long *dbg;   // development build: per-wavefront s_memtime stamps (tools/wino_timeline.py)
+#endif
     int epilogue;
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
 };
@@ -57,15 +77,21 @@ constexpr int PSV = 8;                           // LDS stride of a transformed 
 constexpr int RAW_FLOATS = WP_H * WP_W * PSR;
 constexpr int V_FLOATS = 16 * N_TILES * PSV;     // one buffer (two: the next chunk is transformed during the MFMA loop)
 constexpr int U_FLOATS = 16 * 2 * 64 * 4;        // packed weights of one input chunk x one 64-channel output chunk
-constexpr int X_FLOATS = 32 * 64;                // output-transform exchange: 32 partial sums per lane of a wavefront
-constexpr int WINO_LDS_BYTES = (2 * RAW_FLOATS + 2 * V_FLOATS) * 4;   // 52 352 bytes: two blocks per CU
-static_assert(4 * X_FLOATS <= 2 * V_FLOATS, "the exchange buffer aliases the V buffers");
+constexpr int Y_FLOATS = WT_H * WT_W * 32;       // output exchange: partial 2x2 outputs of one wavefront, [pixel][32 channels]
+constexpr int WINO_LDS_BYTES = 4 * Y_FLOATS * 4;   // 65 536 bytes (the exchange aliases raw / V): two blocks per CU
+static_assert(4 * Y_FLOATS >= 2 * RAW_FLOATS + 2 * V_FLOATS, "LDS layout");
 
 __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
     const int q = total >> 3, r = total & 7;
     const int xcd = bid & 7, slot = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
+
+#ifdef L3C_WINO_TIMELINE
+#define L3C_WINO_STAMP(i) __builtin_amdgcn_sched_barrier(0); dbg_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
+#else
+#define L3C_WINO_STAMP(i)
+#endif
 
 // RELU / RES / SHUFFLE: the epilogue variant, compile-time (no per-element selects).
 template <bool RELU, bool RES, bool SHUFFLE>
@@ -79,18 +105,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     const int half = lane >> 5, lx = lane & 31;
     const int nj = wave & 1, ph = wave >> 1;     // output-channel half; column pair nu = 2 ph, 2 ph + 1 of the transformed tile
     const int n_cc = p.Cin / WCK;
+#ifdef L3C_WINO_TIMELINE
+    unsigned long long dbg_t[12] = {};
+#endif
+    L3C_WINO_STAMP(0)
 
+    // block -> (image, output-channel chunk, sub-grid, tile): divisions by multiplication with host-computed reciprocals
     unsigned w = (unsigned)xcd_remap_w(blockIdx.x, p.total_blocks);
     const unsigned tiles = (unsigned)(p.tiles_x * p.tiles_y);
-    const unsigned tile = w % tiles;
-    w /= tiles;
+    const unsigned w_t = p.div_tiles.div(w);
+    const unsigned tile = w - w_t * tiles;
+    w = w_t;
     const int dl = p.dil_log2, dil = 1 << dl;
     const int phase = (int)(w & ((1u << (2 * dl)) - 1));   // which of the dil x dil sub-grids (dilated conv = dense conv on each)
     w >>= 2 * dl;
-    const int chunk_o = p.n_chunks_o == 1 ? 0 : (int)(w % (unsigned)p.n_chunks_o);
-    const int b = p.n_chunks_o == 1 ? (int)w : (int)(w / (unsigned)p.n_chunks_o);
+    const int b = (int)p.div_chunks.div(w);
+    const int chunk_o = (int)(w - (unsigned)b * (unsigned)p.n_chunks_o);
     const int py = phase >> dl, px = phase & (dil - 1);
-    const int sy0 = (int)(tile / (unsigned)p.tiles_x) * WT_H, sx0 = (int)(tile % (unsigned)p.tiles_x) * WT_W;   // tile origin (sub-grid)
+    const unsigned t_y = p.div_tiles_x.div(tile);
+    const int sy0 = (int)t_y * WT_H, sx0 = (int)(tile - t_y * (unsigned)p.tiles_x) * WT_W;   // tile origin in sub-grid coordinates
 
     constexpr int N_PIECES = WP_H * WP_W * 2;    // 16-byte pieces of a patch (a pixel's 8 channels = 2 pieces)
     constexpr int NIT = (N_PIECES + 255) / 256;
@@ -107,6 +140,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         const int iy = py + dil * (sy0 - 1 + r), ix = px + dil * (sx0 - 1 + ci);
         const bool ok = i < N_PIECES && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
         patch_off[it] = ok ? ((iy * p.W + ix) * p.in_cstride + c4 * 4) * 4 : 0x7ffffff0;
+    }
+    // Store layout of the epilogue: a lane ends up with FOUR values that are adjacent in memory -- plain: pixel e_pl of a
+    // group of 8, channels 4 e_q .. 4 e_q + 3 of the wavefront's 32; pixel shuffle: pixel e_pl, sub-pixel e_s, and the four
+    // conv channels 16 e_g + 4 j + e_s (j = 0..3), which are adjacent OUTPUT channels of that sub-pixel.
+    const int e_pl = lane >> 3, e_q = lane & 7, e_s = (lane >> 1) & 3, e_g = lane & 1;
+    auto e_cw = [&](int j) { return SHUFFLE ? 16 * e_g + 4 * j + e_s : 4 * e_q + j; };   // channel inside the wavefront's 32
+    float bias4[4];   // loaded now: the epilogue must not wait for it
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int co = chunk_o * 64 + nj * 32 + e_cw(j);
+        bias4[j] = co < p.Cout ? p.bias[co] : 0.0f;
     }
     const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff), 0, p.H * p.W * p.in_cstride * 4, 0x00020000);
@@ -128,15 +172,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) fetch_patch_piece(cc, it);
     };
-    auto store_patch = [&](int par) {
+    auto store_pieces = [&](int par, const f32x4 (&regs)[NIT]) {
         float *dst = raw + par * RAW_FLOATS;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int i = tid + it * 256;
             const int c4 = i & 1, pix = i >> 1;
-            if (i < N_PIECES) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = stage_regs[it];
+            if (i < N_PIECES) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = regs[it];
         }
     };
+    auto store_patch = [&](int par) { store_pieces(par, stage_regs); };
     // Input transform B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]).  Wavefront w = (tile row t_ty, output-row pair
     // t_h): lane = (tile column, channel pair) computes rows xi = 2 t_h, 2 t_h + 1 of its tile's transform -- these need the
     // three input rows t_h .. t_h + 2 -- for both channels: 8 tiles x 4 pairs per 32 lanes cover all 64 LDS banks on the
@@ -190,10 +235,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     // staging registers = patch of chunk c + 2 (in flight).  Chunk indices past the end are clamped: the loads stay
     // unconditional, their data is never used.
     auto clamp_cc = [&](int cc) { return cc < n_cc ? cc : n_cc - 1; };
-    fetch_patch(0);
-    store_patch(0);
-    fetch_patch(clamp_cc(1));
+    // ALL of the prologue's loads go out at once -- ONE memory round trip (the co-resident block can cover only so much).
+    // The B operands AFTER the last patch fetch: the loads then are outstanding in the same order as at the top of every later
+    // chunk (patch, then B), and the loop's waits -- which the compiler derives for the worst path -- fit the steady state.
+    f32x4 first_regs[2][NIT];
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+            first_regs[k][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], clamp_cc(k) * WCK * 4, 0));
+    fetch_patch(clamp_cc(2));
+#pragma unroll
+    for (int a = 0; a < 8; ++a) fetch_b(0, a);
+    L3C_WINO_STAMP(6)
+    store_pieces(0, first_regs[0]);
+    store_pieces(1, first_regs[1]);
+    L3C_WINO_STAMP(7)
     __syncthreads();
+    L3C_WINO_STAMP(8)
 #pragma unroll
     for (int i = 0; i < 3; ++i) transform_load(0, i);
 #pragma unroll
@@ -202,12 +261,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         transform_cols(k);
         transform_write(V, k);
     }
-    store_patch(1);
-    fetch_patch(clamp_cc(2));
-    // the B operands AFTER the last patch fetch: the loads then are outstanding in the same order as at the top of every later
-    // chunk (patch, then B), and the loop's waits -- which the compiler derives for the worst path -- fit the steady state
-#pragma unroll
-    for (int a = 0; a < 8; ++a) fetch_b(0, a);
     __syncthreads();
 
     // A fragment of (tile, half): the 4-float group `half`, swizzled like the writes; position stride N_TILES * PSV
@@ -225,6 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     // stored the patch of chunk c + 2, so the last pair's 8 MFMAs run while the barrier releases and the first fragments of
     // chunk c + 1 arrive.
     f32x4 a0[2], a1[2];
+    L3C_WINO_STAMP(1)
     a0[0] = *reinterpret_cast<const f32x4 *>(a_lane + a_pos(0));
     a1[0] = *reinterpret_cast<const f32x4 *>(a_lane + a_pos(1));
     for (int cc = 0; cc < n_cc; ++cc) {
@@ -281,16 +335,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]).  This wavefront holds columns nu = 2 ph, 2 ph + 1 of M:
     // with t_i[n] = sum_xi A^T[i][xi] M[xi][2 ph + n] its share of Y[i][j] is  sum_n t_i[n] A^T[j][2 ph + n]:
     //   ph = 0:  P[i][0] = t_i[0] + t_i[1],  P[i][1] = t_i[1];        ph = 1:  P[i][0] = t_i[0],  P[i][1] = -t_i[0] - t_i[1].
-    // D register r of a fragment belongs to tile (ty, tx) = (r >> 3, (r & 3) + 8 ((r >> 2) & 1) + 4 half): wavefront ph keeps
-    // the partial sums of tile row ph, hands those of the other row to its partner (same nj, other ph) through LDS, adds the
-    // partner's, then bias / ReLU / residual / store.
-    const int cw = nj * 32 + lx;   // channel inside the 64-channel chunk
-    const int co = chunk_o * 64 + cw;
-    const bool co_ok = co < p.Cout;
-    const float bias = co_ok ? p.bias[co] : 0.0f;
-    float mine[8][2][2];
+    // D register r of a fragment belongs to tile (ty, tx) = (r >> 3, (r & 3) + 8 ((r >> 2) & 1) + 4 half), channel lx.  Every
+    // wavefront writes its partial outputs to LDS as [pixel][channel]; wavefront (nj, ph) then finishes tile row ph (output rows
+    // 2 ph, 2 ph + 1) for its 32 channels: it reads both partial sums in the STORE layout -- four values adjacent in memory
+    // per lane -- so that the results leave as 8 x 16-byte stores per lane (full 128-byte lines) instead of 32 x 4-byte ones:
+    // the store instructions, not the bytes, are what the epilogue waits for.
+    L3C_WINO_STAMP(2)
+    const bool interior = py + dil * (sy0 + WT_H - 1) < p.H && px + dil * (sx0 + WT_W - 1) < p.W;
+    const bool fast = interior && p.Cout % (SHUFFLE ? 64 : 4) == 0;   // a lane's four channels: all valid or none
+    constexpr int S = SHUFFLE ? 2 : 1;
+    // output / residual strides of one conv pixel (bytes); the k-th group of 8 pixels of tile row ph: row k >> 2, column 8 (k & 3)
+    const int64_t col_b = (int64_t)S * dil * p.out_cstride * 4, row_b = (int64_t)S * dil * (S * p.W) * p.out_cstride * 4;
+    const int64_t rcol_b = (int64_t)dil * p.res_cstride * 4, rrow_b = (int64_t)dil * p.W * p.res_cstride * 4;
+    const bool lane_ok = chunk_o * 64 + nj * 32 + e_cw(0) < p.Cout;   // Cout % 4 == 0: all four or none
+    f32x4 resv[8];
+    if constexpr (RES) {   // the residual values in the store layout, requested before anything else of the epilogue
+        if (fast) {
+            const float *r_blk = p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px + dil * sx0) * p.res_cstride + p.res_coff + chunk_o * 64;
+            // (a descriptor must stay UNIFORM -- a per-lane field in it costs a waterfall loop per access; lanes whose channels
+            // do not exist get an offset beyond the buffer instead: their accesses are dropped by the range check)
+            const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(r_blk), 0, 0x40000000, 0x00020000);
+            const int r_lane = lane_ok ? (int)(2 * ph * rrow_b + e_pl * rcol_b) + (nj * 32 + 4 * e_q) * 4 : 0x7ffffff0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                resv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        r_rsrc, r_lane, (int)((k >> 2) * rrow_b + (k & 3) * 8 * rcol_b), 0));
+        }
+    }
     {
-        float *X = V + wave * X_FLOATS + lane * 4;   // after the last chunk's barrier nobody reads V any more
+        float *Yw = lds + (ph * 2 + nj) * Y_FLOATS + half * 8 * 32 + lx;   // after the last chunk's barrier raw / V are free
         auto partials = [&](auto ph_c) __attribute__((always_inline)) {
             constexpr int PH = decltype(ph_c)::value;
 #pragma unroll
@@ -306,90 +379,75 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
                     P[i][0] = PH == 0 ? t[i][0] + t[i][1] : t[i][0];
                     P[i][1] = PH == 0 ? t[i][1] : (-t[i][0]) - t[i][1];
                 }
-                if ((r >> 3) == PH) {
+                const int ty = r >> 3, tx = (r & 3) + 8 * ((r >> 2) & 1);   // + 4 half: in Yw
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) mine[r & 7][i][j] = P[i][j];
-                } else {
-                    const f32x4 v = {P[0][0], P[0][1], P[1][0], P[1][1]};
-                    *reinterpret_cast<f32x4 *>(X + (r & 7) * 256) = v;
-                }
+                    for (int j = 0; j < 2; ++j) Yw[((2 * ty + i) * WT_W + 2 * tx + j) * 32] = P[i][j];
             }
         };
         if (ph == 0) partials(std::integral_constant<int, 0>{});
         else partials(std::integral_constant<int, 1>{});
-        __syncthreads();
-        const float *Xp = V + (wave ^ 2) * X_FLOATS + lane * 4;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(Xp + k * 256);
-            mine[k][0][0] += v[0];
-            mine[k][0][1] += v[1];
-            mine[k][1][0] += v[2];
-            mine[k][1][1] += v[3];
-        }
     }
-    // tile row ph of the block: outputs rows 2 ph, 2 ph + 1; tile k: tx = (k & 3) + 8 ((k >> 2) & 1) + 4 half
-    const bool interior = py + dil * (sy0 + WT_H - 1) < p.H && px + dil * (sx0 + WT_W - 1) < p.W;
-    if (interior) {
-        // Buffer addressing: descriptor at the block's first output pixel (uniform), ONE per-lane byte offset, and a scalar
-        // offset per (row, pixel) -- no vector address arithmetic.  Pixel shuffle (dil = 1): conv pixel (oy, ox), channel co
-        // -> pixel (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2 of a 2H x 2W image, i.e. the same walk with doubled
-        // strides and the sub-pixel folded into the lane offset.
-        constexpr int S = SHUFFLE ? 2 : 1;
-        const int64_t col_b = (int64_t)S * dil * p.out_cstride * 4, row_b = (int64_t)S * dil * (S * p.W) * p.out_cstride * 4;
-        float *o_blk = p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * (px + dil * sx0)) * p.out_cstride +
-                       p.out_coff + (SHUFFLE ? chunk_o * 16 : chunk_o * 64);
-        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o_blk, 0, co_ok ? 0x7fffffff : 0, 0x00020000);
-        const int o_lane = (int)(2 * ph * row_b + 8 * half * col_b) +
-                           (SHUFFLE ? ((((cw >> 1) & 1) * (2 * p.W) + (cw & 1)) * p.out_cstride + (cw >> 2)) * 4 : cw * 4);
-        float resv[8][2][2];
-        if constexpr (RES) {   // all 32 residual values of the lane first (one round trip instead of 32)
-            const int64_t rrow_b = (int64_t)dil * p.W * p.res_cstride * 4, rcol_b = (int64_t)dil * p.res_cstride * 4;
-            const float *r_blk = p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px + dil * sx0) * p.res_cstride + p.res_coff + chunk_o * 64;
-            const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(r_blk), 0, co_ok ? 0x7fffffff : 0, 0x00020000);
-            const int r_lane = (int)(2 * ph * rrow_b + 8 * half * rcol_b) + cw * 4;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int tx2 = 2 * ((k & 3) + 8 * ((k >> 2) & 1));
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx)
-                        resv[k][dy][dx] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
-                            r_rsrc, r_lane, (int)(dy * rrow_b + (tx2 + dx) * rcol_b), 0));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int tx2 = 2 * ((k & 3) + 8 * ((k >> 2) & 1));
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    float v = mine[k][dy][dx] + bias;
-                    if constexpr (RELU) v = fmaxf(v, 0.0f);
-                    if constexpr (RES) v = v + resv[k][dy][dx];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, o_lane,
-                                                          (int)(dy * row_b + (tx2 + dx) * col_b), 0);
-                }
-        }
-        return;
-    }
-    // tiles that stick out of the image: per-element bounds checks and addresses
-    if (!co_ok) return;
+    L3C_WINO_STAMP(9)
+    __syncthreads();
+    L3C_WINO_STAMP(10)
+    // pixel k * 8 + e_pl of tile row ph (64 pixels: two image rows of 32), both column pairs' partial sums
+    const float *Yr = lds + nj * Y_FLOATS + (2 * ph * WT_W + e_pl) * 32;
+    float out4[8][4];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int ty = ph, tx = (k & 3) + 8 * ((k >> 2) & 1) + 4 * half;
+        const float *y0 = Yr + k * 8 * 32, *y1 = y0 + 2 * Y_FLOATS;
+        if constexpr (SHUFFLE) {
 #pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
+            for (int j = 0; j < 4; ++j) out4[k][j] = y0[e_cw(j)] + y1[e_cw(j)];
+        } else {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(y0 + 4 * e_q), c = *reinterpret_cast<const f32x4 *>(y1 + 4 * e_q);
 #pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                const int oy = py + dil * (sy0 + 2 * ty + dy), ox = px + dil * (sx0 + 2 * tx + dx);
-                if (oy >= p.H || ox >= p.W) continue;
-                float v = mine[k][dy][dx] + bias;
-                if constexpr (RELU) v = fmaxf(v, 0.0f);
+            for (int j = 0; j < 4; ++j) out4[k][j] = a[j] + c[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            out4[k][j] += bias4[j];
+            if constexpr (RELU) out4[k][j] = fmaxf(out4[k][j], 0.0f);
+        }
+    }
+    if (fast) {
+        // Buffer addressing: descriptor at the block's first output pixel (uniform), ONE per-lane byte offset, a scalar offset
+        // per group of 8 pixels.  Pixel shuffle (dil = 1): conv pixel (oy, ox), channel co -> pixel (2 oy + (co >> 1 & 1),
+        // 2 ox + (co & 1)), channel co >> 2 of a 2H x 2W image: the same walk with doubled strides, the sub-pixel in the lane offset.
+        float *o_blk = p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * (px + dil * sx0)) * p.out_cstride +
+                       p.out_coff + (SHUFFLE ? chunk_o * 16 : chunk_o * 64);
+        const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(o_blk, 0, 0x40000000, 0x00020000);
+        const int o_lane = !lane_ok ? 0x7ffffff0 : (int)(2 * ph * row_b + e_pl * col_b) +
+                           (SHUFFLE ? (((e_s >> 1) * (2 * p.W) + (e_s & 1)) * p.out_cstride + nj * 8 + 4 * e_g) * 4 : (nj * 32 + 4 * e_q) * 4);
+        // ALL eight results first, then the eight stores back to back, each from its own registers: on gfx950 a VALU write to
+        // the data registers of a 16-byte buffer store that was issued just before (register soffset: the compiler sees no
+        // hazard and inserts no wait states) can overtake the store's read of its last dwords -- measured: the 4th dword
+        // of the last lanes of each 16-lane group came out as the NEXT store's value.
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = f32x4{out4[k][0], out4[k][1], out4[k][2], out4[k][3]};
+            if constexpr (RES) v[k] = v[k] + resv[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v[k]),
+                                                   o_rsrc, o_lane, (int)((k >> 2) * row_b + (k & 3) * 8 * col_b), 0);
+        __builtin_amdgcn_sched_barrier(0);
+    } else {
+        // tiles that stick out of the image (or Cout not a multiple of 4): per-element bounds checks and addresses
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int oy = py + dil * (sy0 + 2 * ph + (k >> 2)), ox = px + dil * (sx0 + (k & 3) * 8 + e_pl);
+            if (oy >= p.H || ox >= p.W) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int co = chunk_o * 64 + nj * 32 + e_cw(j);
+                if (co >= p.Cout) continue;
+                float v = out4[k][j];
                 if constexpr (RES) v = v + p.res[(((size_t)b * p.H + oy) * p.W + ox) * p.res_cstride + p.res_coff + co];
                 if constexpr (SHUFFLE) {
                     const size_t oyy = 2 * oy + ((co >> 1) & 1), oxx = 2 * ox + (co & 1);
@@ -398,7 +456,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
                     p.out[(((size_t)b * p.H + oy) * p.W + ox) * p.out_cstride + p.out_coff + co] = v;
                 }
             }
+        }
     }
+#ifdef L3C_WINO_TIMELINE
+    if (p.dbg && lane == 0) {
+        unsigned long long *o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
+        dbg_t[5] = __builtin_amdgcn_s_memtime();
+        dbg_t[3] = dbg_t[1];  dbg_t[4] = dbg_t[2];  dbg_t[2] = dbg_t[0];   // layout of tools/wino_timeline.py: t0..t3 at 2..5
+        o[0] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 16);
+        o[1] = blockIdx.x;
+#pragma unroll
+        for (int i = 2; i < 11; ++i) o[i] = dbg_t[i];
+    }
+#endif
 }
 
 // OIHW 3x3 weights -> U = G g G^T (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) in the kernel's slab order
@@ -433,6 +503,11 @@ __global__ __launch_bounds__(256) void pack_wino_kernel(const float *__restrict_
 }
 
 }  // namespace
+
+#ifdef L3C_WINO_TIMELINE
+static unsigned long long *g_wino_dbg = nullptr;
+extern "C" void l3c_conv_wino_set_debug(void *ptr) { g_wino_dbg = (unsigned long long *)ptr; }
+#endif
 
 extern "C" {
 
@@ -478,6 +553,12 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     const int64_t total = (int64_t)p.tiles_x * p.tiles_y * p.dil * p.dil * p.n_chunks_o * p.B;
     L3C_REQUIRE(total < (1ll << 31), "grid too large");
     p.total_blocks = (int)total;
+    p.div_tiles = wino_div((unsigned)(p.tiles_x * p.tiles_y));
+    p.div_tiles_x = wino_div((unsigned)p.tiles_x);
+    p.div_chunks = wino_div((unsigned)p.n_chunks_o);
+#ifdef L3C_WINO_TIMELINE
+    p.dbg = g_wino_dbg;
+#endif
     typedef void (*kernel_t)(const WinoParams);
     static const kernel_t variants[5] = {conv_wino_kernel<false, false, false>, conv_wino_kernel<true, false, false>,
                                          conv_wino_kernel<false, true, false>, conv_wino_kernel<true, true, false>,
