@@ -224,11 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(dst + j * N_TILES * PSV) = e[k][j];
     };
 
-    f32x16 acc[8];
-#pragma unroll
-    for (int a = 0; a < 8; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    f32x16 acc[8];   // never cleared: the first MFMA of every accumulator takes C = 0 (chunk 0 is a copy of the loop body)
 
     // Prologue.  Invariants at the start of the MFMA loop of chunk c:  V[c & 1] complete and visible; bq = its B operands (in
     // flight); a0[0], a1[0] = the A fragments of its first position pair; raw[(c+1) & 1] = patch of chunk c + 1, visible; the
@@ -281,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     L3C_WINO_STAMP(1)
     a0[0] = *reinterpret_cast<const f32x4 *>(a_lane + a_pos(0));
     a1[0] = *reinterpret_cast<const f32x4 *>(a_lane + a_pos(1));
-    for (int cc = 0; cc < n_cc; ++cc) {
+    auto chunk = [&](const int cc, auto first_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value;
         // No branches on "is there another chunk": the last chunks fetch, store and transform (clamped) data that nobody
         // reads -- cheaper than seventeen uniform branches per chunk, and it keeps the compiler's load counts exact.
         const int cc_b = clamp_cc(cc + 1), cc_p = clamp_cc(cc + 3);
@@ -289,9 +286,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         const float *a_cur = a_lane + par * V_FLOATS;
         const float *a_nxt = a_lane + (par ^ 1) * V_FLOATS;
         float *v_next = V + (par ^ 1) * V_FLOATS;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define L3C_WINO_MFMA(Q, T, A, B)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], acc[Q], 0, 0, 0);                 \
+    acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], (FIRST && (T) == 0) ? zero16 : acc[Q], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
@@ -330,7 +328,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             fetch_b(cc_b, q + 1);
         }
 #undef L3C_WINO_MFMA
-    }
+    };
+    chunk(0, std::true_type{});
+    for (int cc = 1; cc < n_cc; ++cc) chunk(cc, std::false_type{});
 
     // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]).  This wavefront holds columns nu = 2 ph, 2 ph + 1 of M:
     // with t_i[n] = sum_xi A^T[i][xi] M[xi][2 ph + n] its share of Y[i][j] is  sum_n t_i[n] A^T[j][2 ph + n]:
