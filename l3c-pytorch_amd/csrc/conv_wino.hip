@@ -9,11 +9,12 @@
 //   * block = 256 threads = 4 wavefronts on a 4 x 32 output tile = 2 x 16 = 32 Winograd tiles, 64 output channels.
 //     Wavefront (nj, ph) owns 32 tiles x 32 output channels (nj) for the EIGHT positions of two columns nu = 2 ph, 2 ph + 1 of
 //     the transformed tile: 8 accumulator fragments = 128 registers.  A wavefront therefore needs at most 256 registers and a
-//     block 51 KB of LDS: TWO blocks share a CU (two wavefronts per SIMD), and while one block is in its prologue, at its
+//     block 64 KB of LDS: TWO blocks share a CU (two wavefronts per SIMD), and while one block is in its prologue, at its
 //     chunk barrier or in its output transform, the matrix pipe runs the other one's MFMAs -- the hardware interleaves
 //     what a single 512-register wavefront per SIMD could only approximate by hand;
-//   * the output transform is linear, so each wavefront transforms ITS two columns (A^T M_ph A_ph) and the two halves of a
-//     (tile, channel) are added through LDS: wavefront ph finishes tile row ph, 8 x 16-byte LDS writes + reads per lane;
+//   * the output transform is linear, so each wavefront transforms ITS two columns (A^T M_ph A_ph) and writes the partial
+//     2 x 2 outputs to LDS as [pixel][channel]; wavefront (nj, ph) then finishes tile row ph: it reads both halves in the
+//     STORE layout (four channels adjacent in memory per lane) and leaves 8 x 16-byte stores per lane;
 //   * input channels in chunks of 8: the raw 6 x 34 patch of chunk k is fetched into registers during chunk k - 3, written to
 //     LDS during k - 2, transformed during k - 1 by all 256 threads (thread = tile x channel pair x output-row pair: 12
 //     ds_read_b64, 16 packed additions, 8 ds_write_b64, bank-conflict-free) into the other V[16][32 tiles][8] buffer WHILE the
@@ -26,7 +27,6 @@
 // fp32 throughout; the result differs from the direct convolution by rounding only (transform coefficients are 1, 1/2).
 #include "l3c_common.h"
 
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
