@@ -404,11 +404,16 @@ class Bitcoding(object):
 
     def _decode_rgb_pipelined(self, P, targets, payloads, B, C, K, H, W):
         """The RGB scale: channel c's means depend on the decoded values of the channels < c AT THE SAME PIXEL
-        (logistic_mixture.py:262-272), so R, G and B are three serial chains of H*W symbols that only have to stay one
-        chunk of pixels apart.  Pipeline step t: channel c handles chunk t - c -- its table rows are built straight from P
+        (logistic_mixture.py:262-272), so R, G and B are three serial chains of H*W symbols that only have to stay a
+        chunk of pixels apart.  Pipeline step t: channel c handles chunk t - D c -- its table rows are built straight from P
         and the symbols decoded so far (l3c_dmll_cdf_table), then ONE grouped launch (l3c_ac_decode_chunks) resumes the range
-        decoders of all active channels side by side.  Everything stays on the current stream; table validity is a
-        device-side flag, so nothing synchronises with the host.  Time: (chunks + 2) steps instead of 3 * chunks."""
+        decoders of all active channels side by side.  Table validity is a device-side flag, nothing synchronises with
+        the host.
+
+        D = 1 (small batches): everything on the current stream, (chunks + 2) steps of table + decode.
+        D = 2 (16 images or more): the channels stay TWO chunks apart, so the tables of step t + 1 need only the symbols of
+        step t - 1 and are built on the current stream WHILE a side stream decodes step t: (chunks + 4) steps of
+        max(table, decode)."""
         HW = H * W
         n_chunks = max(1, min(self.RGB_CHUNKS, HW // 4096))
         step = -(-HW // n_chunks)
@@ -418,19 +423,40 @@ class Bitcoding(object):
         packed = [ops.pack_streams(payloads[c::C]) for c in range(C)]
         flags = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(C)]
         states = [[ops.ac_decode_state(B), ops.ac_decode_state(B)] for _ in range(C)]
-        for t in range(len(bounds) + C - 1):
+        # the two extra steps cost more than the overlap saves while the tables are small (they grow with the batch, a decode
+        # step does not): D = 2 from 16 images on [measured at 128: 0.726 s instead of 0.825 s]; L3C_DECODE_OVERLAP=0/1 forces
+        overlap = {'0': False, '1': True}.get(os.environ.get('L3C_DECODE_OVERLAP', ''), B >= 16)
+        D = 2 if overlap else 1
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if overlap else main
+        if overlap:
+            side.wait_stream(main)                       # sym, states, packed streams: allocated / filled on the main stream
+        decoded = {}                                     # step -> event: its symbols are in `sym`
+        for t in range(len(bounds) + D * (C - 1)):
+            active = [(c, (t - D * c)) for c in range(C) if (t - D * c) >= 0 and (t - D * c) < len(bounds)]
+            if not active:
+                continue
+            if overlap and t - 2 in decoded:
+                main.wait_event(decoded[t - 2])          # (older steps are ordered before it on the side stream)
             parts = []
-            for c in range(C):
-                j = t - c
-                if not 0 <= j < len(bounds):
-                    continue
+            for c, j in active:
                 p0, n = bounds[j]
                 table = ops.dmll_cdf_table(P, sym, targets, C, K, True, c, p0, n, flags[c])
+                if overlap:
+                    table.record_stream(side)
                 buf, offs, lens = packed[c]
                 parts.append(ops.ac_decode_part(table.reshape(B * n, -1), buf, offs, lens, B, n, flags[c],
                                                 states[c][(j + 1) & 1] if j else None, states[c][j & 1],
                                                 j == len(bounds) - 1, sym, C * HW, c * HW + p0))   # image b, channel c
-            ops.ac_decode_chunks(parts)
+            if overlap:
+                side.wait_stream(main)                   # the tables of this step
+                with torch.cuda.stream(side):
+                    ops.ac_decode_chunks(parts)
+                    decoded[t] = side.record_event()
+            else:
+                ops.ac_decode_chunks(parts)
+        if overlap:
+            main.wait_stream(side)
         return sym
 
     # ---- reference API: one image <-> one file -----------------------------------------------------------------------
