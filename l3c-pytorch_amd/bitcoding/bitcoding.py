@@ -68,6 +68,14 @@ def _staging(nbytes):
     return buf[:nbytes]
 
 
+def rgb_pipeline_schedule(n_chunks, C, D):
+    """Steps of the chunk-pipelined RGB decode: step t handles chunk t - D c of channel c.  Returns a list (one entry per
+    step) of lists of (channel, chunk).  Channel c's chunk j needs the symbols of the channels < c in chunk j: with D = 1
+    they come from the previous step, with D = 2 from two steps back -- the tables of step t + 1 then do not depend on the
+    decode launch of step t and the two can overlap."""
+    return [[(c, t - D * c) for c in range(C) if 0 <= t - D * c < n_chunks] for t in range(n_chunks + D * (C - 1))]
+
+
 class EncodedBatch(object):
     """Device-resident result of `Bitcoding.encode_batch`: per scale (coarse -> fine) the coder output of its B*C streams.
     Nothing has been synchronised or copied to the host until `payloads()` / `to_bytes()` is called."""
@@ -432,8 +440,7 @@ class Bitcoding(object):
         if overlap:
             side.wait_stream(main)                       # sym, states, packed streams: allocated / filled on the main stream
         decoded = {}                                     # step -> event: its symbols are in `sym`
-        for t in range(len(bounds) + D * (C - 1)):
-            active = [(c, (t - D * c)) for c in range(C) if (t - D * c) >= 0 and (t - D * c) < len(bounds)]
+        for t, active in enumerate(rgb_pipeline_schedule(len(bounds), C, D)):
             if not active:
                 continue
             if overlap and t - 2 in decoded:

@@ -114,3 +114,27 @@ def test_rgb_baseline_models_construct_and_load():
     assert MultiscaleTester._parse_recursive_flag('auto', config_parser.parse_builtin('ms', 'cr')) == 0
     with pytest.raises(ValueError):
         MultiscaleTester._parse_recursive_flag('2', config_parser.parse_builtin('ms', 'cr_rgb'))
+
+
+def test_rgb_decode_pipeline_schedule():
+    """Chunk-pipelined RGB decode (bitcoding.rgb_pipeline_schedule): every (channel, chunk) exactly once, in chunk order per
+    channel, and channel c's chunk j at least D steps after channel c - 1's -- D = 2 is what lets the tables of the next
+    step be built while the current step decodes."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import rgb_pipeline_schedule
+    for n_chunks in (1, 2, 5, 16):
+        for C in (1, 3, 5):
+            for D in (1, 2):
+                steps = rgb_pipeline_schedule(n_chunks, C, D)
+                assert len(steps) == n_chunks + D * (C - 1)
+                when = {}
+                for t, active in enumerate(steps):
+                    assert len(active) <= 8          # parts per grouped decoder launch (l3c_ac_decode_chunks)
+                    for c, j in active:
+                        assert (c, j) not in when
+                        when[(c, j)] = t
+                assert sorted(when) == [(c, j) for c in range(C) for j in range(n_chunks)]
+                for (c, j), t in when.items():
+                    if j:
+                        assert when[(c, j - 1)] == t - 1      # a stream's state is carried from one step to the next
+                    if c:
+                        assert when[(c - 1, j)] <= t - D
