@@ -89,8 +89,12 @@ class EncodedBatch(object):
 
     def wait(self):
         """Make the current stream wait for the range-coder launches (they run on side streams)."""
+        cur = torch.cuda.current_stream()
         for ev in self.done:
-            torch.cuda.current_stream().wait_event(ev)
+            cur.wait_event(ev)
+        for _, _, _, out, nbytes in self.scales:     # allocated under the coder's side stream, consumed on this one
+            out.record_stream(cur)
+            nbytes.record_stream(cur)
         return self
 
     def total_payload_bytes(self):
@@ -375,14 +379,27 @@ class Bitcoding(object):
             for r in readers:
                 if r.take(4) != _MAGIC_VALUE_SEP:
                     raise ValueError('invalid file: scale separator missing')
+            # the headers are untrusted input: a wrong C / H / W would make the table and decoder kernels index P and the symbol
+            # buffers out of bounds (the reference fails with a shape error here, bitcoding.py:248-266)
             if uniform:
                 assert bn_prev is None
+                if C != net.config_ms.q.C or H < 1 or W < 1:
+                    raise ValueError('invalid file: coarsest scale header (C={}, H={}, W={})'.format(C, H, W))
+                if max(len(p) for p in payloads) > 2 * H * W + 64:      # > 16 bits per symbol: not a stream of this coder
+                    raise ValueError('invalid file: coarsest scale payload longer than {} symbols can be'.format(H * W))
+                prev_hw = (H, W)
                 buf, offs, lens = ops.pack_streams(payloads)
                 sym = ops.ac_decode(self._uniform_row(dmll.L), buf, offs, lens, B * C, H * W, True,
                                     broadcast_row=True).reshape(B, C, H, W)
             else:
                 P, F_prev = net.get_P(scale, bn_prev, F_prev)
                 P = ops.as_pixel_major(P)
+                n_params = 4 if dmll.rgb_scale else 3
+                expect = (P.shape[-1] // (n_params * K), 2 * prev_hw[0], 2 * prev_hw[1])
+                if (C, H, W) != expect or tuple(P.shape[1:3]) != (H, W):
+                    raise ValueError('invalid file: scale {} header (C, H, W) = {} but the network predicts {}'.format(
+                        scale, (C, H, W), expect))
+                prev_hw = (H, W)
                 targets = self._targets(dmll)
                 if dmll.rgb_scale:
                     sym = self._decode_rgb_pipelined(P, targets, payloads, B, C, K, H, W)
@@ -429,6 +446,10 @@ class Bitcoding(object):
         bounds = [(p0, min(step, HW - p0)) for p0 in range(0, HW, step)]
         sym = torch.zeros(B, C, H, W, dtype=torch.int16, device='cuda')
         packed = [ops.pack_streams(payloads[c::C]) for c in range(C)]
+        # flags[c] is only ever SET (never cleared) by the table kernels.  With the overlapped schedule the table kernel of
+        # step t + 1 (main stream) may set it while the decode launch of step t (side stream) reads it: harmless -- a decode
+        # launch that sees the flag mid-way re-decodes its chunk from state_in with the generic path (state_in != state_out),
+        # and a set flag is exactly what every later launch of that channel must see anyway.
         flags = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(C)]
         states = [[ops.ac_decode_state(B), ops.ac_decode_state(B)] for _ in range(C)]
         # the two extra steps cost more than the overlap saves while the tables are small (they grow with the batch, a decode

@@ -36,7 +36,7 @@ class PackedConv(object):
             self.packed = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_pack_weights', ptr(self.weight), self.Cout, self.Cin, self.KS, ptr(self.packed), stream())
         self.packed_wino = None
-        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 8 == 0:
+        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 8 == 0 and self.Cout % 4 == 0:
             n = _lib.load().l3c_conv_wino_packed_words(self.Cout, self.Cin)
             self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())
@@ -56,7 +56,7 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         out = (torch.empty(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
                else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
     impl = impl or _CONV_IMPL
-    wino = impl == 'mfma' and layer.packed_wino is not None
+    wino = impl == 'mfma' and layer.packed_wino is not None and (layer.Cout % 16 == 0 or not pixel_shuffle)
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
     d.packed_w = ptr(layer.packed_wino if wino else layer.packed if impl == 'mfma' else layer.weight)

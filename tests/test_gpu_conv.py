@@ -196,3 +196,90 @@ def test_winograd_conv_vs_implicit_gemm_and_fp64(dil, Cin, Cout, B, H, W, relu, 
         kw1 = dict(kw, residual=_nhwc(r[1:2]).cuda() if res else None)
         single = ops.conv(_nhwc(x[1:2]).cuda(), layer, **kw1).cpu().permute(0, 3, 1, 2)
         assert torch.equal(single, got[1:2])
+
+
+@pytest.fixture
+def wino_tpb():
+    """l3c_conv_wino_set_tiles_per_block for the duration of a test (0 = pick per launch)."""
+    from l3c_pytorch_amd import _lib
+    lib = _lib.load()
+    prev = lib.l3c_conv_wino_set_tiles_per_block(0)
+    yield lib.l3c_conv_wino_set_tiles_per_block
+    lib.l3c_conv_wino_set_tiles_per_block(prev)
+
+
+TPB_CASES = [
+    # dil, Cout, B, H, W, relu, residual, shuffle        tiles per row of the sub-grid
+    (1, 64, 2, 9, 224, True, False, False),              # 7: groups of 3 + 3 + 1, 2 + 2 + 2 + 1, 5 + 2
+    (1, 64, 1, 12, 130, False, True, False),             # 5, the last one two pixels wide; residual
+    (1, 256, 1, 8, 96, False, False, True),              # 3; pixel shuffle, four output-channel chunks
+    (2, 64, 1, 11, 150, True, True, False),              # sub-grids 75 wide: 3 tiles, ragged in both directions
+    (4, 64, 2, 16, 300, False, False, False),            # sub-grids 75 wide, 4 rows
+    (1, 64, 3, 4, 64, False, False, False),              # 2 tiles, one tile row
+]
+
+
+@pytest.mark.parametrize('dil,Cout,B,H,W,relu,res,shuffle', TPB_CASES)
+def test_winograd_tiles_per_block_is_only_a_schedule(wino_tpb, dil, Cout, B, H, W, relu, res, shuffle):
+    """A block walks 1..n adjacent tiles with its load pipeline running through the tile boundaries (csrc/conv_wino.hip): the
+    result is the same bit for bit for every n -- including groups that end in a tile sticking out of the image -- and within
+    3e-5 of fp64."""
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(dil * 77 + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(Cout, 64, 3, 3, generator=g) / 24
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), dilation=dil, padding=dil)
+    ref = ref.clamp(min=0) if relu else ref
+    ref = ref + r.double() if res else ref
+    ref = F.pixel_shuffle(ref, 2) if shuffle else ref
+    layer = ops.PackedConv(w, b, dilation=dil)
+    kw = dict(relu=relu, residual=_nhwc(r).cuda() if res else None, pixel_shuffle=shuffle)
+    xd = _nhwc(x).cuda()
+    outs = []
+    for n in (1, 2, 3, 5, 64):
+        wino_tpb(n)
+        # poison the output first: every element must be written
+        out = torch.full((B, 2 * H, 2 * W, Cout // 4) if shuffle else (B, H, W, Cout), float('nan'), device='cuda')
+        outs.append(ops.conv(xd, layer, out=out, **kw).cpu())
+    assert (outs[0].permute(0, 3, 1, 2).double() - ref).abs().max().item() < 3e-5
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize('dil,Cout,B,H,W,shuffle', [(1, 64, 2, 256, 384, False), (4, 64, 1, 512, 768, False),
+                                                   (2, 64, 1, 512, 768, False), (1, 256, 2, 128, 192, True)])
+def test_winograd_at_the_headline_layer_sizes(wino_tpb, dil, Cout, B, H, W, shuffle):
+    """The layer shapes of a 768x512 image (R1 body, R0 atrous branches, R2->R1 PixelShuffle tail; tens of
+    thousands of blocks, the multi-tile schedule the bench uses) against the implicit-GEMM kernel everywhere and against
+    fp64 on a window: both within 3e-5 of each other / of fp64 for unit-scale data."""
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(H + dil)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(Cout, 64, 3, 3, generator=g) / 24
+    b = torch.randn(Cout, generator=g)
+    r = None if shuffle else torch.randn(B, Cout, H, W, generator=g)
+    layer = ops.PackedConv(w, b, dilation=dil)
+    kw = dict(residual=_nhwc(r).cuda() if r is not None else None, pixel_shuffle=shuffle)
+    xd = _nhwc(x).cuda()
+    got = ops.conv(xd, layer, **kw)
+    wino, layer.packed_wino = layer.packed_wino, None
+    gemm = ops.conv(xd, layer, **kw)
+    layer.packed_wino = wino
+    assert (got - gemm).abs().max().item() < 3e-5
+    wino_tpb(1)
+    assert torch.equal(ops.conv(xd, layer, **kw), got)
+    # fp64 on a window that contains the image's bottom-right corner
+    hs, ws = H - 40, W - 70
+    pad = 2 * dil
+    ref = F.conv2d(x[:, :, hs - pad:, ws - pad:].double(), w.double(), b.double(), dilation=dil, padding=dil)[:, :, pad:, pad:]
+    if r is not None:
+        ref = ref + r[:, :, hs:, ws:].double()
+    win = got.cpu().permute(0, 3, 1, 2)
+    if shuffle:
+        ref = F.pixel_shuffle(ref, 2)
+        win = win[:, :, 2 * hs:, 2 * ws:]
+    else:
+        win = win[:, :, hs:, ws:]
+    assert win.shape == ref.shape and (win.double() - ref).abs().max().item() < 3e-5
