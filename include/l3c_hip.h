@@ -240,7 +240,7 @@ int l3c_conv_mfma(const l3c_conv_desc *desc_host, l3c_stream_t stream);
  * The same convolution for KS == 3, stride 1, dilation 1, 2 or 4 by Winograd F(2x2, 3x3): 2.25x fewer multiplications, the
  * 16 per-position GEMMs on the fp32 MFMA.  `packed_w` of the descriptor must come from l3c_conv_wino_pack_weights (the
  * transformed weights G g G^T, l3c_conv_wino_packed_words(Cout, Cin) floats).  Differs from l3c_conv_mfma by fp32 rounding.
- * Requirements (L3C_ERR_INVALID_ARG otherwise): Cin % 8 == 0; Cout % 4 == 0 (with PIXEL_SHUFFLE: % 16, dilation 1, no
+ * Requirements (L3C_ERR_INVALID_ARG otherwise): Cin % 16 == 0; Cout % 4 == 0 (with PIXEL_SHUFFLE: % 16, dilation 1, no
  * RELU / RESIDUAL); every channel stride / offset a multiple of 4 and every pointer 16-byte aligned (16-byte accesses);
  * one image of each tensor below 2 GB; no epilogue bits other than L3C_EPI_*.
  * l3c_conv_wino_set_tiles_per_block: a block walks up to n horizontally adjacent 4 x 32 output tiles with its load pipeline

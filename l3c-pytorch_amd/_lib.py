@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libl3c_hip.so')
+# L3C_LIB: a development build of the same library (e.g. the -DL3C_WINO_TIMELINE one of csrc/build.py --timeline)
+LIB_PATH = os.environ.get('L3C_LIB') or os.path.join(_HERE, 'csrc', 'libl3c_hip.so')
 
 c_i64, c_int, c_vp, c_f32 = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p, ctypes.c_float
 

@@ -23,18 +23,20 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra=(), lib=LIB, objdir='_obj'):
+    """extra / lib / objdir: development variants next to the product build (--timeline: per-wavefront s_memtime stamps in
+    conv_wino_kernel for tools/wino_timeline.py, loaded through the L3C_LIB environment variable)."""
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objs = []
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
-    os.makedirs(os.path.join(HERE, '_obj'), exist_ok=True)
+    os.makedirs(os.path.join(HERE, objdir), exist_ok=True)
     procs = []
     for src in SOURCES:
         s = os.path.join(HERE, src)
-        o = os.path.join(HERE, '_obj', src.replace('.hip', '.o'))
+        o = os.path.join(HERE, objdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + os.environ.get('HIPCC_EXTRA', '').split() + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + list(extra) + os.environ.get('HIPCC_EXTRA', '').split() + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -44,13 +46,19 @@ def build(force=False, verbose=False):
             raise RuntimeError('hipcc failed on {}:\n{}'.format(src, out.decode()))
         if verbose and out:
             print(out.decode())
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    if force or procs or _stale(lib, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', lib] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == '__main__':
-    print(build(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv))
+    kw = dict(force='--force' in sys.argv, verbose='--verbose' in sys.argv or '-v' in sys.argv)
+    if '--timeline' in sys.argv:
+        kw.update(extra=['-DL3C_WINO_TIMELINE'], lib=os.path.join(HERE, 'libl3c_hip_timeline.so'), objdir='_obj_timeline')
+    if '--wino-probe' in sys.argv:       # development: timing probes of conv_wino_kernel with parts of it removed (wrong results)
+        n = sys.argv[sys.argv.index('--wino-probe') + 1]
+        kw.update(extra=['-DL3C_WINO_PROBE=' + n], lib=os.path.join(HERE, 'libl3c_hip_probe{}.so'.format(n)), objdir='_obj_probe' + n)
+    print(build(**kw))

@@ -98,6 +98,12 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
+// Development probes (csrc/build.py --wino-probe N; results are WRONG, only the time means something): bit 0 no patch loads,
+// 1 no patch stores to LDS, 2 no input transform, 3 no weight loads inside the loop, 4 no chunk barrier, 5 no output stores,
+// 6 (correct results) the patch fetch at the end of the chunk.  Never defined in the product build.
+#ifndef L3C_WINO_PROBE
+#define L3C_WINO_PROBE 0
+#endif
 #ifdef L3C_WINO_TIMELINE
 #define L3C_WINO_STAMP(i) __builtin_amdgcn_sched_barrier(0); dbg_t[i] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0);
 #else
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     constexpr int N_PIECES = WP_H * WP_W * 2;    // 16-byte pieces of a patch (a pixel's 8 channels = 2 pieces)
     constexpr int NIT = (N_PIECES + 255) / 256;
     static_assert(NIT == 2, "the patch prefetch pieces are dealt out by hand below");
-    f32x4 stage_regs[NIT];
+    f32x4 stage_regs[2][NIT];   // two patches in flight: set g & 1 holds the patch of chunk g + 2, fetched during chunk g - 2
     // this thread's patch elements: byte offsets relative to the image base, for the tile the prefetch pointer is in.  The
     // image is one buffer descriptor: a piece outside it (zero padding) gets an offset beyond the buffer and reads as zero.
     // The lane index, recomputed where it is used rarely (v_mbcnt; the opaque mask keeps the compiler from hoisting the
@@ -198,8 +204,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         bq[a] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                               u_rsrc, u_lane, (cc * U_FLOATS + ((a >> 1) * 4 + (a & 1)) * 512) * 4, 0));
     };
-    auto fetch_patch_piece = [&](int it) {
-        stage_regs[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], pf_cc * WCK * 4, 0));
+    auto fetch_patch_piece = [&](int set, int it) {
+        if constexpr (L3C_WINO_PROBE & 1) return;
+        stage_regs[set][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], pf_cc * WCK * 4, 0));
     };
     auto store_pieces = [&](int par, const f32x4 (&regs)[NIT]) {
         float *dst = raw_buf(par);
@@ -210,7 +217,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             if (i < N_PIECES) *reinterpret_cast<f32x4 *>(&dst[pix * PSR + c4 * 4]) = regs[it];
         }
     };
-    auto store_patch = [&](int par) { store_pieces(par, stage_regs); };
     // Input transform B^T d B (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]).  Wavefront w = (tile row t_ty, output-row pair
     // t_h): lane = (tile column, channel pair) computes rows xi = 2 t_h, 2 t_h + 1 of its tile's transform -- these need the
     // three input rows t_h .. t_h + 2 -- for both channels: 8 tiles x 4 pairs per 32 lanes cover all 64 LDS banks on the
@@ -219,13 +225,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     const int t_tx = lane >> 2, t_cq = lane & 3, t_ty = wave & 1, t_h = wave >> 1;
     // rows xi = 2 t_h, 2 t_h + 1 of B^T d as  e0 = x - z,  e1 = s y + z  with (x, y, z; s) = (d0, d1, d2; +1) for t_h = 0 and
     // (d2, d3, d1; -1) for t_h = 1: ONE instruction stream for all four wavefronts, the difference is in the LDS addresses
-    const int t_src = ((2 * t_ty) * WP_W + 2 * t_tx) * PSR + 2 * t_cq;
-    const int t_row[3] = {2 * t_h, 1 + 2 * t_h, 2 - t_h};
+    const int t_src = (2 * t_tx) * PSR + 2 * t_cq;                  // the lane's part of the source address (ONE register) ...
+    const int t_row[3] = {2 * t_ty + 2 * t_h, 2 * t_ty + 1 + 2 * t_h, 2 * t_ty + 2 - t_h};   // ... and the wavefront's: patch rows
     const float t_s = t_h ? -1.0f : 1.0f;
     const int t_dst = (t_ty * 16 + t_tx) * PSV + (((t_cq >> 1) ^ (t_tx >> 3)) * 4) + (t_cq & 1) * 2 + (2 * t_h * 4) * N_TILES * PSV;
     f32x2 d[3][4], e[2][4];
     auto transform_load = [&](int par, int i) {   // i = 0, 1, 2: x, y, z
-        const float *src = raw_buf(par) + t_src + t_row[i] * WP_W * PSR;
+        int row_off = t_row[i] * WP_W * PSR;
+        asm volatile("" : "+s"(row_off));   // added per use: three precomputed per-lane addresses would cost two more registers
+        const float *src = raw_buf(par) + t_src + row_off;
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2 *>(src + j * PSR);
     };
@@ -253,11 +261,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x2 *>(dst + j * N_TILES * PSV) = e[k][j];
     };
 
-    f32x16 acc[8];   // never cleared: the first MFMA of every accumulator of a tile takes C = 0
+    f32x16 acc[8];   // never cleared: the first MFMA of every accumulator of a tile takes C = 0 ...
+    // ... except the one of position (xi, nu) = (1, 1), which starts from the BIAS: A^T has a 1 in column 1 of both rows, so
+    // M[1][1] enters all four outputs of a tile with weight 1 -- the bias rides through the output transform for free.  That
+    // position is operand 3 of the ph = 0 wavefronts; D-layout: lane = output channel.
+    const int co_lane = chunk_o * 64 + nj * 32 + lx;
+    const float bias_init = (ph == 0 && co_lane < p.Cout) ? p.bias[co_lane] : 0.0f;
+    auto init_bias = [&]() {   // (volatile: sixteen copies made here, per tile -- not hoisted into sixteen registers held forever)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(bias_init));
+            acc[3][r] = v;
+        }
+    };
 
     // Prologue.  Invariants at the start of the MFMA loop of chunk g:  V[g & 1] complete and visible; bq = its B operands (in
     // flight); a0[0], a1[0] = the A fragments of its first position pair; raw[(g+1) & 1] = patch of chunk g + 1, visible; the
-    // staging registers = patch of chunk g + 2 (in flight); the prefetch pointer is at chunk g + 3.
+    // staging sets g & 1 and (g+1) & 1 = the patches of chunks g + 2 and g + 3 (in flight: a patch has TWO chunks' time to
+    // arrive -- with one the loop stalled on HBM latency whenever a chunk touched new cache lines [timeline: the loop of a
+    // tile whose prefetches were dummies ran in 24 k cycles, with real ones in 32 k]); the prefetch pointer is at chunk g + 4.
+    // The number of chunks is even (Cin % 16 == 0), so g & 1 = cc & 1 is a compile-time constant of each chunk body.
     // ALL of the prologue's loads go out at once -- ONE memory round trip (the co-resident block can cover only so much).
     // The B operands AFTER the last patch fetch: the loads then are outstanding in the same order as at the top of every later
     // chunk (patch, then B), and the loop's waits -- which the compiler derives for the worst path -- fit the steady state.
@@ -271,16 +295,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         pf_advance();
     }
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) fetch_patch_piece(it);
-    pf_advance();
+    for (int k = 0; k < 2; ++k) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) fetch_patch_piece(k, it);
+        pf_advance();
+    }
 #pragma unroll
     for (int a = 0; a < 8; ++a) fetch_b(0, a);
-    L3C_WINO_STAMP(6)
+    L3C_WINO_STAMP(1)
     store_pieces(0, first_regs[0]);
     store_pieces(1, first_regs[1]);
-    L3C_WINO_STAMP(7)
+    L3C_WINO_STAMP(2)
     __syncthreads();
-    L3C_WINO_STAMP(8)
+    L3C_WINO_STAMP(3)
 #pragma unroll
     for (int i = 0; i < 3; ++i) transform_load(0, i);
 #pragma unroll
@@ -306,27 +333,26 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     // stored the patch of chunk g + 2, so the last pair's 8 MFMAs run while the barrier releases and the first fragments of
     // chunk g + 1 arrive.
     f32x4 a0[2], a1[2];
-    L3C_WINO_STAMP(1)
+    L3C_WINO_STAMP(4)
     a0[0] = *reinterpret_cast<const f32x4 *>(v_buf(0) + a_lane + a_pos(0));
     a1[0] = *reinterpret_cast<const f32x4 *>(v_buf(0) + a_lane + a_pos(1));
     // Nothing of the prologue stays in flight: the tile loop is entered from here and from its own back edge, and the compiler
     // sizes the waits at a join for the path with the FEWEST operations behind the awaited load -- with the prologue's loads
     // still counted, the first chunk of every later tile would wait for the previous tile's output stores to be acknowledged.
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    int g = 0;   // global chunk counter: LDS buffer parity
-    auto chunk = [&](const int cc, auto first_c) __attribute__((always_inline)) {
+    auto chunk = [&](const int cc, auto first_c, auto par_c) __attribute__((always_inline)) {
         constexpr bool FIRST = decltype(first_c)::value;
+        constexpr int par = decltype(par_c)::value;   // = cc & 1 = g & 1
         // No branches around loads: past the block's last chunk the pipeline fetches, stores and transforms data that nobody
         // reads -- cheaper than seventeen uniform branches per chunk, and it keeps the compiler's load counts exact.
         const int cc_b = cc + 1 == n_cc ? 0 : cc + 1;   // the next chunk's weights: the next tile starts over with chunk 0
-        const int par = g & 1;
         const float *a_cur = v_buf(par) + a_lane;
         const float *a_nxt = v_buf(par ^ 1) + a_lane;
         float *v_next = v_buf(par ^ 1);
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #define L3C_WINO_MFMA(Q, T, A, B)                                                                  \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], (FIRST && (T) == 0) ? zero16 : acc[Q], 0, 0, 0); \
+    acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32((A)[T], (B)[T], (FIRST && (T) == 0 && (Q) != 3) ? zero16 : acc[Q], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
@@ -335,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             if (pp == 3) {
                 // everything chunk g + 1 needs from this wave is issued: patch g + 2 stored, V[(g+1) & 1] written -- the
                 // barrier (LDS operations only: the loads in flight stay in flight), then the first fragments of chunk g + 1
-                __syncthreads();
+                if constexpr (!(L3C_WINO_PROBE & 16)) __syncthreads();
                 a0[nb] = *reinterpret_cast<const f32x4 *>(a_nxt + a_pos(0));
                 a1[nb] = *reinterpret_cast<const f32x4 *>(a_nxt + a_pos(1));
             }
@@ -344,29 +370,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             L3C_WINO_MFMA(q + 1, 0, A1, B1)
             if (pp < 3) a1[nb] = *reinterpret_cast<const f32x4 *>(a_cur + a_pos(q + 3));
             L3C_WINO_MFMA(q, 1, A0, B0)
-            if (pp == 0) store_patch(par);   // patch g + 2 -> raw[g & 1] (its previous patch was transformed during g - 1)
-            if (pp == 1) transform_load(par ^ 1, 1);
-            if (pp == 2) transform_cols(0);
+            if (pp == 0 && !(L3C_WINO_PROBE & 2)) store_pieces(par, stage_regs[par]);   // patch g + 2 -> raw[g & 1] (its previous patch was transformed during g - 1)
+            if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 1);
+            if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_cols(0);
             L3C_WINO_MFMA(q + 1, 1, A1, B1)
-            if (pp == 0) fetch_patch_piece(0);
-            if (pp == 1) transform_rows(0);
-            if (pp == 2) transform_write(v_next, 0);
+            if (pp == 0 && !(L3C_WINO_PROBE & 64)) fetch_patch_piece(par, 0);   // patch g + 4 into the set just stored
+            if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_rows(0);
+            if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_write(v_next, 0);
             L3C_WINO_MFMA(q, 2, A0, B0)
-            if (pp == 0) transform_load(par ^ 1, 0);
-            if (pp == 1) transform_rows(1);
-            if (pp == 2) transform_cols(1);
+            if (pp == 0 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 0);
+            if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_rows(1);
+            if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_cols(1);
             L3C_WINO_MFMA(q + 1, 2, A1, B1)
-            if (pp == 0) fetch_patch_piece(1);
-            if (pp == 0) transform_load(par ^ 1, 2);
-            if (pp == 1) pf_advance();       // the prefetch pointer moves on (into the next tile: new column offsets)
-            if (pp == 2) transform_write(v_next, 1);
+            if (pp == 0 && !(L3C_WINO_PROBE & 64)) fetch_patch_piece(par, 1);
+            if (pp == 0 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 2);
+            if (pp == 1 && !(L3C_WINO_PROBE & 64)) pf_advance();       // the prefetch pointer moves on (into the next tile: new column offsets)
+            if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_write(v_next, 1);
             L3C_WINO_MFMA(q, 3, A0, B0)
-            fetch_b(cc_b, q);
+            if constexpr (!(L3C_WINO_PROBE & 8)) fetch_b(cc_b, q);
             L3C_WINO_MFMA(q + 1, 3, A1, B1)
-            fetch_b(cc_b, q + 1);
+            if constexpr (!(L3C_WINO_PROBE & 8)) fetch_b(cc_b, q + 1);
+            if constexpr ((L3C_WINO_PROBE & 64) != 0) {   // variant (correct results): the patch fetch BEHIND the chunk's weight loads
+                if (pp == 3) {
+                    fetch_patch_piece(par, 0);
+                    fetch_patch_piece(par, 1);
+                    pf_advance();
+                }
+            }
         }
 #undef L3C_WINO_MFMA
-        ++g;
     };
 
     constexpr int S = SHUFFLE ? 2 : 1;
@@ -388,11 +420,16 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         RES ? p.H * p.W * p.res_cstride * 4 : 0, 0x00020000);
     const int r_row0 = ((py + dil * sy0) * p.W + px) * p.res_cstride * 4;
     const bool rows_in = py + dil * (sy0 + WT_H - 1) < p.H;
-    const auto bias_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.bias), 0, p.Cout * 4, 0x00020000);
 
     for (int t = 0; t < n_t; ++t) {
-        chunk(0, std::true_type{});
-        for (int cc = 1; cc < n_cc; ++cc) chunk(cc, std::false_type{});
+        L3C_WINO_STAMP(5)
+        init_bias();
+        chunk(0, std::true_type{}, std::integral_constant<int, 0>{});
+        chunk(1, std::false_type{}, std::integral_constant<int, 1>{});
+        for (int cc = 2; cc < n_cc; cc += 2) {
+            chunk(cc, std::false_type{}, std::integral_constant<int, 0>{});
+            chunk(cc + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        }
 
         // ---- output transform Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]).  This wavefront holds columns nu = 2 ph, 2 ph + 1 of
         // M: with t_i[n] = sum_xi A^T[i][xi] M[xi][2 ph + n] its share of Y[i][j] is  sum_n t_i[n] A^T[j][2 ph + n]:
@@ -403,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         // in place, and reads the sums back in the STORE layout -- four values adjacent in memory per lane -- so that the results
         // leave as 8 x 16-byte stores per lane (full 128-byte lines): the store instructions, not the bytes, are what the
         // epilogue waits for.  The exchange (2 x 16 KB) lives in the LDS run the pipeline has just released (see the LDS map).
-        L3C_WINO_STAMP(2)
+        L3C_WINO_STAMP(6)
         // Everything the epilogue derives from the lane index is recomputed for every tile (the empty asm hides the index from
         // the loop-invariant code motion): held across the chunk loop these values would push the accumulators out of the
         // register file.
@@ -415,14 +452,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         const int e_pl = ln >> 3, e_q = ln & 7, e_s = (ln >> 1) & 3, e_g = ln & 1;
         auto e_cw = [&](int j) { return SHUFFLE ? 16 * e_g + 4 * j + e_s : 4 * e_q + j; };   // channel inside the wavefront's 32
         const bool lane_ok = chunk_o * 64 + nj * 32 + e_cw(0) < p.Cout;   // Cout % 4 (pixel shuffle: % 16) == 0: all four or none
-        f32x4 bias4;   // requested now, used last (a channel beyond Cout reads as 0)
-        if constexpr (SHUFFLE) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                bias4[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bias_rsrc, (chunk_o * 64 + nj * 32 + e_cw(j)) * 4, 0, 0));
-        } else {
-            bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bias_rsrc, (chunk_o * 64 + nj * 32 + 4 * e_q) * 4, 0, 0));
-        }
         const int o_lane = !lane_ok ? OOB : 2 * ph * row_b + e_pl * col_b +
                            (SHUFFLE ? (((e_s >> 1) * (2 * p.W) + (e_s & 1)) * p.out_cstride + nj * 8 + 4 * e_g) * 4 : (nj * 32 + 4 * e_q) * 4);
         const int r_lane = lane_ok ? 2 * ph * rrow_b + e_pl * rcol_b + (nj * 32 + 4 * e_q) * 4 : OOB;
@@ -434,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             const bool ok = interior | ((oy_l + dil * (k >> 2) < p.H) & (ox_l + dil * (sx0 + (k & 3) * 8) < p.W));
             return ok ? base : OOB;
         };
-        float *Yn = lds + (((g - 1) & 1) ? LDS_FLOATS - 2 * Y_FLOATS : 0) + nj * Y_FLOATS;   // [128 pixels][32 channels] of this nj
+        float *Yn = lds + (LDS_FLOATS - 2 * Y_FLOATS) + nj * Y_FLOATS;   // [128 pixels][32 channels] of this nj (the last chunk of a tile is odd)
         float *Yw = Yn + half * 8 * 32 + lx;
         float own[8][2][2];   // this wavefront's share of its own tile row (D registers r = 8 ph .. 8 ph + 7)
         auto hand_over = [&](auto ph_c) __attribute__((always_inline)) {
@@ -473,9 +502,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
                 resv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                         r_rsrc, lane_off(r_lane, k), r_tile + (k >> 2) * rrow_b + (k & 3) * 8 * rcol_b, 0));
         }
-        L3C_WINO_STAMP(9)
+        L3C_WINO_STAMP(7)
         __syncthreads();
-        L3C_WINO_STAMP(10)
+        L3C_WINO_STAMP(8)
         {
             float *Yo = Yw + 2 * ph * WT_W * 32;   // this wavefront's own tile row
             float theirs[8][2][2];
@@ -506,16 +535,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             if constexpr (SHUFFLE) v[k] = f32x4{y0[e_cw(0)], y0[e_cw(1)], y0[e_cw(2)], y0[e_cw(3)]};
             else v[k] = *reinterpret_cast<const f32x4 *>(y0 + 4 * e_q);
         }
+        L3C_WINO_STAMP(9)
         // the next tile's pipeline writes into the exchange's LDS: every wavefront must have read its sums first
         if (t + 1 < n_t) __syncthreads();
         int o_off[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[k][j] += bias4[j];
+            for (int j = 0; j < 4; ++j)
                 if constexpr (RELU) v[k][j] = fmaxf(v[k][j], 0.0f);
-            }
             if constexpr (RES) v[k] = v[k] + resv[k];
             o_off[k] = lane_off(o_lane, k);
         }
@@ -526,24 +554,25 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         const int o_tile = o_row0 + sx0 * col_b;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v[k]),
+        for (int k = 0; k < ((L3C_WINO_PROBE & 32) ? 1 : 8); ++k)
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned,
+                                                                      (L3C_WINO_PROBE & 32) ? ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7])) : v[k]),
                                                    o_rsrc, o_off[k], o_tile + (k >> 2) * row_b + (k & 3) * 8 * col_b, 0);
         __builtin_amdgcn_sched_barrier(0);
-        // the first A fragments of the next tile once more (V[g & 1] has been complete since the last chunk's barrier): read
+        // the first A fragments of the next tile once more (V[0] has been complete since the last chunk's barrier): read
         // again here, they need no registers during the output transform
-        a0[0] = *reinterpret_cast<const f32x4 *>(v_buf(g & 1) + a_lane + a_pos(0));
-        a1[0] = *reinterpret_cast<const f32x4 *>(v_buf(g & 1) + a_lane + a_pos(1));
+        a0[0] = *reinterpret_cast<const f32x4 *>(v_buf(0) + a_lane + a_pos(0));
+        a1[0] = *reinterpret_cast<const f32x4 *>(v_buf(0) + a_lane + a_pos(1));
     }
 #ifdef L3C_WINO_TIMELINE
-    if (p.dbg && lane == 0) {
-        unsigned long long *o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 12;
-        dbg_t[5] = __builtin_amdgcn_s_memtime();
-        dbg_t[3] = dbg_t[1];  dbg_t[4] = dbg_t[2];  dbg_t[2] = dbg_t[0];   // layout of tools/wino_timeline.py: t0..t3 at 2..5
-        o[0] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 16);
-        o[1] = blockIdx.x;
+    if (p.dbg && lane == 0) {   // stamps of the block's first prologue and LAST tile (tools/wino_timeline.py)
+        unsigned long long *o = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 16;
+        dbg_t[10] = __builtin_amdgcn_s_memtime();
+        o[12] = __builtin_amdgcn_s_getreg((16 - 1) << 11 | 0 << 6 | 4) | (__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) << 16);
+        o[13] = blockIdx.x;
+        o[14] = (unsigned long long)n_t;
 #pragma unroll
-        for (int i = 2; i < 11; ++i) o[i] = dbg_t[i];
+        for (int i = 0; i < 11; ++i) o[i] = dbg_t[i];
     }
 #endif
 }
@@ -596,7 +625,7 @@ int64_t l3c_conv_wino_packed_words(int Cout, int Cin) { return (int64_t)((Cout +
 
 int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream) {
     L3C_REQUIRE(w_oihw && packed, "null pointer");
-    L3C_REQUIRE(Cout > 0 && Cin > 0 && Cin % 8 == 0, "Cin must be a multiple of 8");
+    L3C_REQUIRE(Cout > 0 && Cin > 0 && Cin % 16 == 0, "Cin must be a multiple of 16");
     const int64_t total = l3c_conv_wino_packed_words(Cout, Cin);
     int64_t g = (total + 255) / 256;
     hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, l3c::as_stream(stream), w_oihw,
@@ -611,7 +640,7 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     L3C_REQUIRE(d->dilation == 1 || d->dilation == 2 || d->dilation == 4, "dilation must be 1, 2 or 4");
     L3C_REQUIRE(d->dilation == 1 || !(d->epilogue & L3C_EPI_PIXEL_SHUFFLE), "pixel shuffle with dilation not provided");
     L3C_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Cout > 0, "bad shape");
-    L3C_REQUIRE(d->Cin > 0 && d->Cin % WCK == 0, "Cin must be a multiple of 8");
+    L3C_REQUIRE(d->Cin > 0 && d->Cin % (2 * WCK) == 0, "Cin must be a multiple of 16 (an even number of 8-channel chunks)");
     L3C_REQUIRE(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0, "input channel stride/offset must be multiples of 4");
     L3C_REQUIRE(d->out_cstride % 4 == 0 && d->out_coff % 4 == 0, "output channel stride/offset must be multiples of 4 (16-byte stores)");
     L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || (d->res_cstride % 4 == 0 && d->res_coff % 4 == 0),

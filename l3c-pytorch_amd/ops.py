@@ -36,7 +36,7 @@ class PackedConv(object):
             self.packed = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_pack_weights', ptr(self.weight), self.Cout, self.Cin, self.KS, ptr(self.packed), stream())
         self.packed_wino = None
-        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 8 == 0 and self.Cout % 4 == 0:
+        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 16 == 0 and self.Cout % 4 == 0:
             n = _lib.load().l3c_conv_wino_packed_words(self.Cout, self.Cin)
             self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())

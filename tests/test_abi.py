@@ -84,7 +84,17 @@ def test_argument_validation_of_every_family_precedes_any_launch():
     d.KS, d.dilation = 3, 3
     assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'dilation must be' in err()
     d.dilation, d.Cin = 1, 60
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 8' in err()
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 16' in err()
+    d.Cin, d.out_cstride = 64, 62
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '16-byte stores' in err()
+    d.out_cstride, d.out = 64, fake + 4
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '16-byte aligned' in err()
+    d.out, d.Cout = fake, 62
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 4' in err()
+    d.Cout, d.epilogue = 64, 0x100
+    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'unknown epilogue bits' in err()
+    d.epilogue = 0
+    assert lib.l3c_conv_wino_set_tiles_per_block(2) == 0 and lib.l3c_conv_wino_set_tiles_per_block(0) == 2
     assert lib.l3c_conv_wino_packed_words(64, 64) == 16 * 64 * 64 and lib.l3c_conv_wino_packed_words(120, 64) == 16 * 128 * 64
     # container
     sc = (_lib.ContainerScale * 1)(_lib.ContainerScale(fake, fake, 6, 5, 8, 8))

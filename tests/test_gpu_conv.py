@@ -154,7 +154,7 @@ WINO_CASES = [
     (2, 64, 64, 2, 19, 37, False, True, False),        # dilated: dense conv on the 2x2 interleaved sub-grids
     (4, 64, 64, 1, 21, 50, True, False, False),
     (4, 64, 64, 1, 3, 5, False, False, False),         # image smaller than the dilation pattern
-    (1, 8, 64, 1, 9, 9, False, False, False),          # a single input-channel chunk
+    (1, 16, 64, 1, 9, 9, False, False, False),         # the smallest Cin: one pair of input-channel chunks
     (1, 64, 64, 1, 1, 1, False, False, False),
 ]
 

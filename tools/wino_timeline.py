@@ -1,7 +1,12 @@
 #!/usr/bin/env python
-"""Development probe: per-wavefront s_memtime stamps of conv_wino_kernel -- needs csrc/conv_wino.hip compiled with
--DL3C_WINO_TIMELINE (HIPCC_EXTRA=-DL3C_WINO_TIMELINE python l3c-pytorch_amd/csrc/build.py --force); prints how long the
-prologue, the MFMA loop and the epilogue of a wavefront take and how the two wavefronts of a SIMD overlap."""
+"""Development probe: per-wavefront s_memtime stamps of conv_wino_kernel.  Needs the timeline build of the library:
+
+    python l3c-pytorch_amd/csrc/build.py --timeline
+    L3C_LIB=l3c-pytorch_amd/csrc/libl3c_hip_timeline.so python tools/wino_timeline.py [--res] [--tpb N] [--B 32]
+
+Prints how long the prologue of a block and the MFMA loop / output transform of its LAST tile take (shader cycles), and how
+busy the matrix pipe would be if every loop ran 32 x 8 MFMAs of 64 cycles."""
+import argparse
 import ctypes
 import os
 import sys
@@ -12,52 +17,47 @@ import torch  # noqa: E402
 import l3c_pytorch_amd  # noqa: E402,F401
 from l3c_pytorch_amd import ops, _lib  # noqa: E402
 
-B, H, W, C = 32, 256, 384, 64
+ap = argparse.ArgumentParser()
+ap.add_argument('--res', action='store_true')
+ap.add_argument('--tpb', type=int, default=0)
+ap.add_argument('--B', type=int, default=32)
+a = ap.parse_args()
+B, H, W, C = a.B, 256, 384, 64
 g = torch.Generator().manual_seed(0)
 w = torch.randn(C, C, 3, 3, generator=g) / 24
 layer = ops.PackedConv(w, torch.randn(C, generator=g))
 x = torch.randn(B, H, W, C, generator=g).cuda()
-res = torch.randn(B, H, W, C, generator=g).cuda() if '--res' in sys.argv else None
+res = torch.randn(B, H, W, C, generator=g).cuda() if a.res else None
+lib = _lib.load()
+lib.l3c_conv_wino_set_tiles_per_block(a.tpb)
 for _ in range(3):
     ops.conv(x, layer, relu=res is None, residual=res)
 torch.cuda.synchronize()
-n_blocks = (H // 4) * (W // 32) * B
-dbg = torch.zeros(n_blocks * 4 * 12, dtype=torch.int64, device='cuda')
-lib = _lib.load()
+n_blocks = (H // 4) * (W // 32) * B                    # upper bound (tpb = 1)
+dbg = torch.zeros(n_blocks * 4 * 16, dtype=torch.int64, device='cuda')
 lib.l3c_conv_wino_set_debug.argtypes = [ctypes.c_void_p]
 lib.l3c_conv_wino_set_debug(ctypes.c_void_p(dbg.data_ptr()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 ops.conv(x, layer, relu=res is None, residual=res)
+e1.record()
 torch.cuda.synchronize()
 lib.l3c_conv_wino_set_debug(None)
-d = dbg.cpu().numpy().reshape(-1, 12)
-d = d[d[:, 5] != 0]
-hw, blk, t0, t1, t2, t3, p1, p2, p3, e1, e2, _ = d.T
-print('waves with stamps', len(d), 'of', n_blocks * 4)
-for name, v in (('P: decode+issue loads', p1 - t0), ('P: wait+store patches', p2 - p1), ('P: barrier 1', p3 - p2), ('P: transform+barrier 2', t1 - p3), ('E: partial sums + X write', e1 - t2), ('E: barrier', e2 - e1), ('E: X read, final, stores', t3 - e2), ('prologue', t1 - t0), ('loop', t2 - t1), ('epilogue', t3 - t2), ('total', t3 - t0)):
-    print('{:26s} mean {:9.0f}  p10 {:9.0f}  p50 {:9.0f}  p90 {:9.0f} ticks'.format(name, v.mean(), *np.percentile(v, [10, 50, 90])))
-key = hw >> 4                      # (xcc, se, sh, cu, pipe, simd): everything but the wave slot
-slot = hw & 0xf
-print('wave slots used:', np.unique(slot), ' SIMDs:', len(np.unique(key)))
-tot = dict(span=0, loop1=0, loop2=0, idle_slot=0, gaps=[])
-for k in np.unique(key):
-    m = key == k
-    sp0, sp1 = t0[m].min(), t3[m].max()
-    ev = []
-    for a, b_ in zip(t1[m], t2[m]):
-        ev.append((a, 1)); ev.append((b_, -1))
-    ev.sort()
-    depth, last = 0, ev[0][0]
-    for t, dlt in ev:
-        if depth >= 1: tot['loop1'] += t - last
-        if depth >= 2: tot['loop2'] += t - last
-        depth += dlt; last = t
-    tot['span'] += sp1 - sp0
-    for sl in (0, 1):
-        ms = m & (slot == sl)
-        o = np.argsort(t0[ms])
-        a, b_ = t0[ms][o], t3[ms][o]
-        tot['gaps'] += list(a[1:] - b_[:-1])
-g = np.array(tot['gaps'])
-print('per SIMD: some wave in its MFMA loop {:.1%} of the time, two at once {:.1%}'.format(tot['loop1'] / tot['span'], tot['loop2'] / tot['span']))
-print('slot turnover (end of a wave -> start of the next in the same slot): mean {:.0f}  p10 {:.0f}  p50 {:.0f}  p90 {:.0f} ticks'.format(
-    g.mean(), *np.percentile(g, [10, 50, 90])))
+ms = e0.elapsed_time(e1)
+d = dbg.cpu().numpy().reshape(-1, 16)
+d = d[d[:, 10] != 0]
+t = d[:, :11].astype(np.float64)
+n_t = d[:, 14]
+print('waves with stamps {}  tiles per block: {}  launch {:.3f} ms = {:.1f} algorithmic TFLOP/s (stamped build)'.format(
+    len(d), np.unique(n_t), ms, 2.0 * B * H * W * C * C * 9 / ms / 1e9))
+rows = [('P: decode + issue loads', t[:, 1] - t[:, 0]), ('P: wait + store patches', t[:, 2] - t[:, 1]),
+        ('P: barrier', t[:, 3] - t[:, 2]), ('P: transform + barrier', t[:, 4] - t[:, 3]), ('prologue', t[:, 4] - t[:, 0]),
+        ('last tile: MFMA loop', t[:, 6] - t[:, 5]), ('E: hand over + residual fetch', t[:, 7] - t[:, 6]),
+        ('E: barrier A', t[:, 8] - t[:, 7]), ('E: sums in place + read back', t[:, 9] - t[:, 8]),
+        ('E: (barrier B) bias, stores', t[:, 10] - t[:, 9]), ('epilogue', t[:, 10] - t[:, 6]),
+        ('block total', t[:, 10] - t[:, 0])]
+for name, v in rows:
+    print('{:32s} mean {:9.0f}  p10 {:9.0f}  p50 {:9.0f}  p90 {:9.0f}'.format(name, v.mean(), *np.percentile(v, [10, 50, 90])))
+tile = ((t[:, 10] - t[:, 4]) / n_t).mean()
+print('per tile (loop + epilogue, averaged over the block): {:.0f} cycles for 16384 cycles of MFMA -> two wavefronts per SIMD '
+      'keep the matrix pipe {:.1%} busy at most'.format(tile, min(1.0, 2 * 16384 / tile)))
