@@ -2,21 +2,30 @@
 """bench.py -- MPix/s of the L3C encode hot path (net forward + fused logistic-mixture CDF head + HIP range coder) on
 synthetic 768x512 RGB batches, BASELINE.json's metric.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--config headline|dataset|large]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of B images per GPU: the images are already resident in HBM when the
-timed region starts, and the step ends with every stream's bytes and byte counts in HBM (file assembly / PCIe are not
-part of `value`).  Images shard one-batch-per-GPU with no data-path collective ("replicas only",
-SURVEY.md section 8e): scaling is weak, `value` = all ranks' pixels / max-over-ranks time.
+--config headline (default; BASELINE.json configs 2/3): one "step" = one pass of the hot path over one batch of B images per
+GPU: the images are already resident in HBM when the timed region starts, and the step ends with every stream's bytes and
+byte counts in HBM (file assembly / PCIe are not part of `value`).
+--config dataset (config 4): a step = the rank's share of a set of 500 differently sized images (sizes drawn like the
+reference's Open Images preprocessing), END TO END from host uint8 images to `.l3c` byte strings on the host.
+--config large (config 5): RGB Shared baseline 0306_0002 (cr_rgb_shared.cf, auto_recurse 3, padding to 16): a step = forward +
+bpsp of one 3000x2000 image (-> 4 auto-crops of 1500x1000) and one 2000x1500 image (not cropped: auto_crop.py:44-47).
+Images shard with no data-path collective ("replicas only"): scaling is weak, `value` = all ranks'
+pixels / max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline      dominant kernel = the fp32 MFMA conv (v_mfma_f32_32x32x2_f32; Winograd F(2x2,3x3) for the 3x3 layers):
-                algorithmic (direct-convolution) FLOPs of all its launches in the timed region / their summed HIP-event
-                durations, against the 157.3 TFLOP/s dense fp32 MFMA peak (+ the executed share of the matrix pipe)
-  cpu_baseline  the oracle (CPU restatement of the reference path: torch-CPU convs + torch CDF tables + C range coder)
-                timed on this box's host cores on ONE 768x512 image of the same workload (rank 0, N=1 only)
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries (headline config)
+  roofline      dominant kernel = conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32): `achieved` = the FLOPs the
+                matrix pipe EXECUTES (16/36 of the direct convolution's) summed over its launches in the timed region / their
+                summed HIP-event durations; `peak` = 157.3 TFLOP/s dense fp32 MFMA at 2.4 GHz; the direct-convolution
+                (algorithmic) rate, the PMC-measured HBM traffic per launch and the counter-based pipe occupancy
+                (profiles/r02_pmc_bench.json) ride along
+  cpu_baseline  the oracle (or, where /root/reference exists, the reference itself) timed on this box's host cores
+  parity        image 0 of the batch against the oracle: max |P - P_oracle| per scale (get_P on the oracle's bottlenecks),
+                symbol flips, and the HIP `.l3c` file's size against the oracle's
+  decode        the last batch decoded back from its files (outside the timed region), lossless check, batch-1 latency
 """
 import argparse
 import json
@@ -30,29 +39,40 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 H, W = 512, 768
-FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
 ALGO_FLOP_PER_PX = 1367796         # conv stack of the L3C forward, FLOP per image pixel
+RGB_SHARED_FLOP_PER_PX = 869168    # RGB Shared with auto_recurse 3
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=6)
-    ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--batch', type=int, default=128, help='images per GPU per step')
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
+    ap.add_argument('--config', choices=('headline', 'dataset', 'large'), default='headline')
+    ap.add_argument('--batch', type=int, default=128, help='headline: images per GPU per step')
+    ap.add_argument('--images', type=int, default=500, help='dataset: images in the set (all ranks together)')
+    ap.add_argument('--max-batch', type=int, default=16, help='dataset: images of one padded shape per forward pass')
     ap.add_argument('--coder-cus', type=int, default=0, help='compute units reserved for the range coder (0 = share all CUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--no-decode', action='store_true', help='skip the (untimed-region) decode leg')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events of the roofline leg')
-    return ap.parse_args()
+    ap.add_argument('--stub-step', action='store_true',
+                    help='tests only: no GPU, gloo, a sleep instead of the hot path -- exercises the launch / barrier / max-over-ranks / JSON path')
+    a = ap.parse_args(argv)
+    defaults = {'headline': (6, 2), 'dataset': (1, 1), 'large': (4, 1)}[a.config]
+    a.steps = defaults[0] if a.steps is None else a.steps
+    a.warmup = defaults[1] if a.warmup is None else a.warmup
+    return a
 
 
-def build_path(device, coder_cus=0):
+def build_path(ms_config='cr', coder_cus=0):
     import l3c_pytorch_amd  # noqa: F401
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
     from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
     from l3c_pytorch_amd.helpers import config_parser, synthetic
-    cfg = config_parser.parse_builtin('ms', 'cr')
+    cfg = config_parser.parse_builtin('ms', ms_config)
     sd = synthetic.make_state_dict(cfg, 0)
     bp = MultiscaleBlueprint(cfg)
     bp.net.load_state_dict(sd, strict=True)
@@ -60,26 +80,174 @@ def build_path(device, coder_cus=0):
     return cfg, sd, bp, Bitcoding(bp, coder_cus=coder_cus), synthetic
 
 
-def cpu_baseline(sd, synthetic):
-    """The oracle's encode of one 768x512 image on the host cores (bounded: one image, ~10-30 s)."""
-    from oracle import bitcoding as obc
-    img = synthetic.make_image(H, W, 0, 'natural').unsqueeze(0).long()
-    cores = torch.get_num_threads()
-    t0 = time.time()
+# ---- distributed plumbing (shared by every config and by the CPU stub the tests run) ----------------------------------------
+
+
+class Ranks(object):
+    """One process per GPU under torch.distributed.run; RCCL ('nccl') for the barrier and the max-over-ranks time only."""
+
+    def __init__(self, stub=False):
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.stub = stub
+        self.device = None
+        if not stub:
+            torch.cuda.set_device(self.local_rank)
+            self.device = torch.device('cuda', self.local_rank)
+        # launched by torch.distributed.run (any world size, 1 included): a process group
+        self.distributed = self.world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
+        if self.distributed:
+            import torch.distributed as dist
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+            if stub:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.device)   # RCCL
+            self.dist = dist
+
+    def sync(self):
+        if not self.stub:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        self.sync()
+        if self.distributed:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, seconds):
+        if not self.distributed:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if not self.stub else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, values):
+        if not self.distributed:
+            return list(values)
+        t = torch.tensor(list(values), dtype=torch.float64, device=self.device if not self.stub else 'cpu')
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return [float(v) for v in t.tolist()]
+
+    def close(self):
+        if self.distributed:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(ranks, step, steps, warmup, before_timed=None):
+    """W untimed steps, then exactly K steps between barriers; -> (max-over-ranks seconds, last step's result)."""
+    res = None
+    for _ in range(warmup):
+        res = step()
+    ranks.barrier()
+    if before_timed:
+        before_timed()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = step()
+    ranks.barrier()
+    return ranks.max_over_ranks(time.perf_counter() - t0), res
+
+
+def contract(args, ranks, value, elapsed, **extra):
+    d = {'metric': 'MPix/s encode (net+CDF+AC) on 768x512 RGB', 'value': round(value, 3), 'unit': 'MPix/s',
+         'n_gpus': ranks.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+    d.update(extra)
+    return d
+
+
+# ---- headline: batches of 768x512 ------------------------------------------------------------------------------------------------
+
+
+def load_pmc_table():
+    """profiles/r02_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
+    --pmc run of THIS script, reduced by tools/pmc_bench.py.  None when it has not been collected."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r02_pmc_bench.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_leg(records, args, elapsed):
+    by = {}
+    for key, flops, nbytes, e0, e1 in records:
+        d = by.setdefault(key, [0.0, 0.0, 0, 0.0])
+        d[0] += flops
+        d[1] += e0.elapsed_time(e1) * 1e-3
+        d[2] += 1
+        d[3] += nbytes
+    dom = max(by, key=lambda k: by[k][1])
+    flops, secs, n, nbytes = by[dom]
+    all_f = sum(v[0] for v in by.values())
+    all_s = sum(v[1] for v in by.values())
+    # Winograd F(2x2,3x3) executes 16 multiplications per 2x2 output tile and channel pair where the direct form needs 36
+    executed = 16.0 / 36.0 if dom.startswith('conv_wino') else 1.0
+    ach = flops * executed / secs / 1e12
+    roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+            'note': ('achieved = FLOPs the matrix pipe executes (Winograd F(2x2,3x3): 16/36 of the direct convolution\'s) / HIP-event time '
+                     'of the launches in the timed region; peak = dense fp32 MFMA at 2.4 GHz' if executed < 1 else
+                     'implicit GEMM: algorithmic = executed FLOPs'),
+            'algorithmic_tflops': round(flops / secs / 1e12, 2), 'algorithmic_frac': round(flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+            'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 3),
+            'algorithmic_bytes_per_launch': int(nbytes / n), 'traffic': None,
+            'all_mfma_convs': {'algorithmic_tflops': round(all_f / all_s / 1e12, 2), 'seconds_per_step': round(all_s / args.steps, 5),
+                               'share_of_step': round(all_s / elapsed, 3)},
+            'per_kernel': {k: {'algorithmic_tflops': round(v[0] / v[1] / 1e12, 1), 'share_of_step': round(v[1] / elapsed, 3),
+                               'launches_per_step': v[2] // args.steps, 'algorithmic_gb_per_launch': round(v[3] / v[2] / 1e9, 3)}
+                           for k, v in sorted(by.items())}}
+    pmc = load_pmc_table()
+    if pmc and pmc.get('batch') == args.batch:
+        k = pmc.get('kernels', {}).get(dom)
+        if k:
+            roof['traffic'] = int(k['hbm_bytes_per_launch'])
+            roof['traffic_note'] = ('PMC, rocprofv3 passes over this script (profiles/r02_pmc_bench.json): FETCH_SIZE + WRITE_SIZE per '
+                                    'launch, averaged over the kernel\'s launches of a step; = {:.3f} x the algorithmic bytes'.format(
+                                        k['hbm_bytes_per_launch'] / (nbytes / n)))
+            for name in ('mfma_busy_frac', 'effective_clock_ghz'):
+                if name in k:
+                    roof['pmc_' + name] = k[name]
+            for kk, vv in pmc.get('kernels', {}).items():
+                if kk in roof['per_kernel']:
+                    roof['per_kernel'][kk]['pmc_hbm_gb_per_launch'] = round(vv['hbm_bytes_per_launch'] / 1e9, 3)
+    return roof
+
+
+def parity_leg(bp, bc, imgs, enc, sd, oracle_file):
+    """Image 0 of the batch against the oracle (the checker): P through get_P on the oracle's bottlenecks, symbols of the
+    forward pass, and the size of its `.l3c` file against the oracle's (when the CPU baseline leg produced one)."""
+    from oracle import net as onet
+    img0 = imgs[0:1]
     with torch.no_grad():
-        data = obc.encode(img, sd)
-    dt = time.time() - t0
-    return {'value': round(H * W / 1e6 / dt, 5), 'unit': 'MPix/s', 'cores': cores, 'kind': 'port',
-            'sample': '1 image 768x512 (natural-like synthetic), oracle.bitcoding.encode: torch-CPU forward + torch CDF '
-                      'tables + C range coder, {:.1f} s, {} bytes'.format(dt, len(data)),
-            'seconds': round(dt, 2)}
+        ref = onet.forward(img0.float().cpu(), sd)
+    out = bp.net(img0.float())
+    res = {'image': 0, 'max_abs_P': [], 'max_rel_P': [],
+           'symbol_flips': sum(int((out.S[s + 1].cpu() != ref.S[s + 1]).sum()) for s in range(3))}
+    f_prev = None
+    for s in (2, 1, 0):
+        P, f_prev = bp.net.get_P(s, ref.bn[s + 1].cuda(), f_prev)
+        d = (P.cpu().double() - ref.P[s].double()).abs().max()
+        res['max_abs_P'].insert(0, float(d))
+        res['max_rel_P'].insert(0, float(d / ref.P[s].double().abs().max()))
+    hip_file = enc.to_bytes()[0]
+    res['hip_bytes'] = len(hip_file)
+    if oracle_file is not None:
+        res['oracle_bytes'] = len(oracle_file)
+        res['size_delta'] = len(hip_file) - len(oracle_file)
+        res['framing_equal'] = hip_file[:13] == oracle_file[:13]
+    res['tolerance'] = 'P within 1e-5 (north_star); file within 64 B of the oracle\'s'
+    res['ok'] = bool(max(res['max_abs_P']) < 1e-5 and abs(res.get('size_delta', 0)) <= 64)
+    return res
 
 
 def decode_leg(bc, enc, imgs, compute_stream):
     """Secondary figure (SURVEY.md section 8d "also decode MPix/s"), outside the timed region: decode the last coded batch
-    back from its `.l3c` byte strings (host) to pixels in HBM and check it is lossless.  The range decoder is a serial
-    chain per stream (one wavefront each; the R, G, B chains of an image run a chunk of pixels apart), so the time depends
-    little on the batch size."""
+    back from its `.l3c` byte strings (host) to pixels in HBM and check it is lossless; plus the latency of one image."""
     SYMBOLS_PER_PX = 4.640625           # 3 P0 + 5 (P1 + P2 + P3) symbols per image pixel, SURVEY.md section 8d
     with torch.cuda.stream(compute_stream):
         files = enc.to_bytes()
@@ -89,39 +257,30 @@ def decode_leg(bc, enc, imgs, compute_stream):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         lossless = bool(torch.equal(dec.to(torch.uint8), imgs.to(torch.uint8)))
+        bc.decode_batch(files[:1])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dec1, _ = bc.decode_batch(files[:1])
+        torch.cuda.synchronize()
+        dt1 = time.perf_counter() - t0
+        lossless = lossless and bool(torch.equal(dec1.to(torch.uint8), imgs[:1].to(torch.uint8)))
     B = len(files)
     return {'value': round(B * H * W / 1e6 / dt, 3), 'unit': 'MPix/s', 'batch': B, 'seconds': round(dt, 3),
             'lossless': lossless, 'msym_per_s_aggregate': round(B * H * W * SYMBOLS_PER_PX / 1e6 / dt, 1),
-            'longest_chain_symbols': H * W,
+            'longest_chain_symbols': H * W, 'ns_per_symbol_of_the_longest_chain': round(dt1 / (H * W) * 1e9 / 1.125, 1),
+            'batch1_seconds': round(dt1, 4), 'batch1_mpix_per_s': round(H * W / 1e6 / dt1, 3),
             'note': 'host .l3c bytes -> pixels in HBM; latency-bound: serial chains of {} symbols per RGB channel, the three '
-                    'channels pipelined a chunk of pixels apart'.format(H * W)}
+                    'channels pipelined a chunk of pixels apart (18 chunk steps for 16 chunks: x 1.125)'.format(H * W)}
 
 
-def main():
-    args = parse_args()
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
-    # launched by torch.distributed.run (any world size, 1 included): RCCL for the barrier and the max-over-ranks time
-    distributed = world > 1 or ('RANK' in os.environ and 'MASTER_PORT' in os.environ)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)   # RCCL; one process per GPU
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus {} != WORLD_SIZE {}'.format(args.gpus, world), file=sys.stderr)
-
-    cfg, sd, bp, bc, synthetic = build_path(device, args.coder_cus)
+def run_headline(args, ranks):
+    cfg, sd, bp, bc, synthetic = build_path('cr', args.coder_cus)
     from l3c_pytorch_amd import _lib, ops
     B = args.batch
     # synthetic images (seed = global image index), resident in HBM before the timed region
-    imgs = torch.stack([synthetic.make_image(H, W, rank * B + i, 'natural') for i in range(B)]).to(device)
+    imgs = torch.stack([synthetic.make_image(H, W, ranks.rank * B + i, 'natural') for i in range(B)]).to(ranks.device)
     imgs_f = imgs.float().contiguous()
     torch.cuda.synchronize()
-
     compute_stream = bc.compute_stream if bc.compute_stream is not None else torch.cuda.current_stream()
 
     def step():
@@ -129,96 +288,164 @@ def main():
             out = bp.net(imgs_f)
             return bc.encode_batch(imgs_f, out=out)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
+    want_events = ranks.rank == 0 and not args.no_kernel_events
 
-    for _ in range(args.warmup):
-        enc = step()
-    barrier()
-    want_events = rank == 0 and not args.no_kernel_events
-    ops.PROFILE = [] if want_events else None
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        enc = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def arm():
+        ops.PROFILE = [] if want_events else None
+
+    elapsed, enc = timed(ranks, step, args.steps, args.warmup, before_timed=arm)
     records, ops.PROFILE = ops.PROFILE, None
+    value = ranks.world * B * args.steps * H * W / 1e6 / elapsed
 
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    total_px = world * B * args.steps * H * W
-    value = total_px / 1e6 / elapsed
-
-    # bpsp of the coded batch (file bytes incl. framing) and lossless check of one image on rank 0
     with torch.cuda.stream(compute_stream):
         sizes = enc.file_sizes().cpu().numpy()
-    bpsp = float(sizes.sum()) * 8 / (B * 3 * H * W)
-
+    bits, subpx = ranks.sum_over_ranks([float(sizes.sum()) * 8, B * 3 * H * W])
     result = None
-    if rank == 0:
-        roofline = None
-        if records:
-            by = {}
-            for key, flops, e0, e1 in records:
-                d = by.setdefault(key, [0.0, 0.0, 0])
-                d[0] += flops
-                d[1] += e0.elapsed_time(e1) * 1e-3
-                d[2] += 1
-            dom = max(by, key=lambda k: by[k][1])
-            flops, secs, n = by[dom]
-            all_f = sum(v[0] for v in by.values())
-            all_s = sum(v[1] for v in by.values())
-            traffic = None   # HBM bytes per launch of the dominant kernel, from the committed PMC passes (profiles/)
-            try:
-                with open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic_conv3x3.json')) as f:
-                    traffic = int(json.load(f)['hbm_bytes_per_flop'] * flops / n)
-            except (OSError, KeyError, ValueError):
-                pass
-            # the Winograd kernel executes 16 multiplications per 2x2 output tile and channel pair where the direct form needs
-            # 36: `achieved` stays ALGORITHMIC (direct-convolution) FLOPs / time, so it can exceed the MFMA peak; the share
-            # of the matrix pipe really in use is reported next to it
-            executed = 16.0 / 36.0 if dom.startswith('conv_wino') else 1.0
-            roofline = {'bound': 'mfma', 'kernel': dom, 'achieved': round(flops / secs / 1e12, 2),
-                        'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                        'mfma_executed_tflops': round(flops * executed / secs / 1e12, 2),
-                        'mfma_utilisation': round(flops * executed / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
-                        'note': ('Winograd F(2x2,3x3): achieved = algorithmic (direct-conv) FLOPs / time; the MFMA executes 16/36 of '
-                                 'them' if executed < 1 else 'implicit GEMM: algorithmic = executed FLOPs'),
-                        'traffic': traffic, 'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2),
-                        'algorithmic_gflop_per_launch': round(flops / n / 1e9, 3),
-                        'all_mfma_convs': {'achieved': round(all_f / all_s / 1e12, 2), 'seconds_per_step': round(all_s / args.steps, 5),
-                                           'share_of_step': round(all_s / elapsed, 3)},
-                        'per_kernel': {k: {'tflops': round(v[0] / v[1] / 1e12, 1), 'share_of_step': round(v[1] / elapsed, 3),
-                                           'launches_per_step': v[2] // args.steps} for k, v in sorted(by.items())}}
-        decode = None
-        if world == 1 and not args.no_decode:
-            decode = decode_leg(bc, enc, imgs, compute_stream)
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(sd, synthetic)
+    if ranks.rank == 0:
+        roofline = roofline_leg(records, args, elapsed) if records else None
+        decode = decode_leg(bc, enc, imgs, compute_stream) if ranks.world == 1 and not args.no_decode else None
+        cpu, oracle_file = None, None
+        if ranks.world == 1 and not args.no_cpu_baseline:
+            from oracle import cpu_baseline
+            cpu, oracle_file = cpu_baseline.run(sd, imgs[0].cpu())
+        parity = None
+        if ranks.world == 1 and not args.no_parity:
+            with torch.cuda.stream(compute_stream):
+                parity = parity_leg(bp, bc, imgs_f, bc.encode_batch(imgs_f[0:1]), sd, oracle_file)
         name, ncu, arch = _lib.device_info()
-        result = {
-            'metric': 'MPix/s encode (net+CDF+AC) on 768x512 RGB', 'value': round(value, 3), 'unit': 'MPix/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'L3C 0306_0001 (cr.cf, synthetic seeded checkpoint), batch of 768x512 synthetic RGB per '
-                                   'GPU: net forward + fused logistic-mixture CDF head + HIP range coder -> bytes in HBM',
-                       'batch_per_gpu': B, 'image': '768x512', 'coder_cus': args.coder_cus, 'sharding': 'images, replicas only (no collective)'},
-            'bpsp': round(bpsp, 4), 'flop_per_px': ALGO_FLOP_PER_PX,
-            'end_to_end_tflops': round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / world, 2),
-            'device': '{} ({}, {} CUs)'.format(name, arch, ncu),
-            'peak_hbm_gb': round(torch.cuda.max_memory_allocated() / 1e9, 1),
-            'roofline': roofline, 'cpu_baseline': cpu, 'decode': decode,
-        }
+        result = contract(
+            args, ranks, value, elapsed,
+            config={'workload': 'L3C 0306_0001 (cr.cf, synthetic seeded checkpoint), batch of 768x512 synthetic RGB per GPU: net forward + '
+                                'fused logistic-mixture CDF head + HIP range coder -> bytes in HBM',
+                    'batch_per_gpu': B, 'image': '768x512', 'coder_cus': args.coder_cus, 'sharding': 'images, replicas only (no collective)'},
+            bpsp=round(bits / subpx, 4), flop_per_px=ALGO_FLOP_PER_PX,
+            end_to_end_algorithmic_tflops=round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / ranks.world, 2),
+            device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
+            roofline=roofline, cpu_baseline=cpu, parity=parity, decode=decode)
+    return result
+
+
+# ---- dataset: 500 differently sized images, end to end from host images to host files ---------------------------------------------
+
+
+def run_dataset(args, ranks):
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')       # (read at HIP start-up; set by main() before the first HIP call)
+    cfg, sd, bp, bc, synthetic = build_path('cr', args.coder_cus)
+    from l3c_pytorch_amd import _lib
+    from l3c_pytorch_amd.helpers import dataset_codec, pad, sharding
+    sizes = dataset_codec.draw_sizes(args.images)
+    mine = sharding.shard_indices(args.images, ranks.rank, ranks.world)
+    imgs = {i: synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural') for i in mine}     # host uint8
+
+    def step():
+        return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch)
+
+    elapsed, (files, n_shapes, n_launches) = timed(ranks, step, args.steps, args.warmup)
+    pixels = sum(sizes[i][0] * sizes[i][1] for i in mine)
+    bits = sum(len(files[i]) for i in mine) * 8
+    tot_px, tot_bits = ranks.sum_over_ranks([pixels, bits])
+    value = tot_px * args.steps / 1e6 / elapsed
+    # round trip of two of the rank's images (outside the timed region)
+    for i in mine[:2]:
+        dec, padding = bc.decode_batch([files[i]])
+        out = pad.undo_pad(dec, *padding[0]) if any(padding[0]) else dec
+        assert torch.equal(out.cpu()[0], imgs[i].long()), 'round trip failed for image {}'.format(i)
+    result = None
+    if ranks.rank == 0:
+        name, ncu, arch = _lib.device_info()
+        result = contract(
+            args, ranks, value, elapsed, metric='MPix/s encode (host uint8 image -> .l3c bytes on the host) on a heterogeneous image set',
+            config={'workload': 'L3C 0306_0001, {} synthetic natural-like images, sizes drawn like the reference\'s Open Images preprocessing '
+                                '(short side 512..1024), END TO END: H2D, pad to 8, forward, fused heads, grouped range-coder launches, file '
+                                'assembly on the device, one D2H'.format(args.images),
+                    'images': args.images, 'images_on_rank0': len(mine), 'distinct_padded_shapes_on_rank0': n_shapes,
+                    'forward_launches_on_rank0': n_launches, 'max_batch': args.max_batch,
+                    'sharding': 'image i -> rank i mod N (helpers/sharding.py), replicas only'},
+            bpsp=round(tot_bits / (3 * tot_px), 4), megapixels=round(tot_px / 1e6, 1), round_trip_of_2_images='lossless',
+            device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))
+    return result
+
+
+# ---- large: RGB Shared baseline on 3000x2000 (auto-cropped) and 2000x1500 images ----------------------------------------------------
+
+
+def run_large(args, ranks):
+    cfg, sd, bp, bc, synthetic = build_path('cr_rgb_shared', 0)
+    from l3c_pytorch_amd import _lib, auto_crop
+    from l3c_pytorch_amd.helpers import pad
+    recurse = 3
+    fac = 2 ** (cfg.num_scales + recurse)                   # 16 (multiscale_tester.py:222-225)
+    shapes = [(2000, 3000), (1500, 2000)]
+    batches, px, crops_of = [], 0, []
+    for k, (h, w) in enumerate(shapes):
+        img = synthetic.make_image(h, w, 1000 + 2 * ranks.rank + k, 'natural').unsqueeze(0)
+        crops = list(auto_crop.iter_crops(img))             # unpatched threshold: H*W > 2000*1500 -> 2x2 crops
+        crops_of.append(len(crops))
+        padded = [pad.pad(c, fac, mode='constant')[0] for c in crops]
+        batches.append((torch.cat(padded).float().to(ranks.device), [int(c.shape[-2] * c.shape[-1]) for c in crops]))
+        px += h * w
+    torch.cuda.synchronize()
+
+    def step():
+        bpsps = []
+        for x, areas in batches:
+            comb = auto_crop.CropLossCombinator()
+            for n, area in enumerate(areas):                # bpsp per crop over its unpadded sub-pixels, area-weighted (auto_crop.py:139-152)
+                out = bp.forward(x[n:n + 1], recurse)
+                loss = bp.get_loss(out, num_subpixels_before_pad=3 * area)
+                comb.add(float(sum(loss.recursive_bpsps)), area)
+            bpsps.append(comb.get_bpsp())
+        return bpsps
+
+    elapsed, bpsps = timed(ranks, step, args.steps, args.warmup)
+    value = ranks.world * px * args.steps / 1e6 / elapsed
+    result = None
+    if ranks.rank == 0:
+        name, ncu, arch = _lib.device_info()
+        result = contract(
+            args, ranks, value, elapsed, metric='MPix/s forward + bpsp (RGB Shared baseline, auto_recurse 3) on large images',
+            config={'workload': 'RGB Shared 0306_0002 (cr_rgb_shared.cf, synthetic seeded checkpoint), auto_recurse 3, pad to 16: per GPU and '
+                                'step one 3000x2000 image (auto-cropped into {} crops) and one 2000x1500 image ({} crop): Pillow-exact bicubic '
+                                'pyramid on the device + decoder + heads + NLL; forward + bpsp only, like the reference'.format(*crops_of),
+                    'images_per_gpu_per_step': 2, 'crop_threshold_px': auto_crop._NEEDS_CROP_DIM, 'sharding': 'images, replicas only'},
+            bpsp=[round(b, 4) for b in bpsps], flop_per_px=RGB_SHARED_FLOP_PER_PX,
+            end_to_end_algorithmic_tflops=round(value * 1e6 * RGB_SHARED_FLOP_PER_PX / 1e12 / ranks.world, 2),
+            device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))
+    return result
+
+
+# ---- stub (tests): the launch / timing / reduction / JSON path without a GPU --------------------------------------------------------
+
+
+def run_stub(args, ranks):
+    from l3c_pytorch_amd.helpers import sharding
+    mine = sharding.shard_indices(4 * ranks.world + 1, ranks.rank, ranks.world)      # uneven on purpose
+
+    def step():
+        time.sleep(0.01 * (1 + ranks.rank))              # rank r is slower than rank r - 1: the reduction must pick the slowest
+        return len(mine)
+
+    elapsed, n = timed(ranks, step, args.steps, args.warmup)
+    px, = ranks.sum_over_ranks([n * H * W])
+    if ranks.rank != 0:
+        return None
+    return contract(args, ranks, px * args.steps / 1e6 / elapsed, elapsed, data='stub (no GPU work)',
+                    config={'workload': 'stub step: sleep 10 ms x (rank + 1)', 'items': 4 * ranks.world + 1})
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.config == 'dataset':
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # several small forward passes side by side, see Bitcoding.encode_many
+    ranks = Ranks(stub=args.stub_step)
+    if args.gpus != ranks.world and ranks.rank == 0 and ranks.world > 1:
+        print('warning: --gpus {} != WORLD_SIZE {}'.format(args.gpus, ranks.world), file=sys.stderr)
+    run = run_stub if args.stub_step else {'headline': run_headline, 'dataset': run_dataset, 'large': run_large}[args.config]
+    result = run(args, ranks)
+    if ranks.rank == 0:
         print(json.dumps(result))
-    if distributed:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    ranks.close()
     return result
 
 

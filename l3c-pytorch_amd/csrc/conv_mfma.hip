@@ -1,8 +1,10 @@
 // conv_mfma.hip -- fp32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32 (gfx950), plus a plain-VALU cross-check.
 //
 // Two kernels: conv_lds_kernel ("v3", all 3x3 layers: both MFMA operands from LDS, weights by LDS-DMA) further down, and
-// conv_mfma_kernel ("v1", 5x5 stride 2 and 1x1: weights per wave from L2) described first.  Flags 0x100..0x800 in
-// `epilogue` select development-probe instantiations / the v1 kernel for A/B measurements (tools/conv_probe.py).
+// conv_mfma_kernel ("v1", 5x5 stride 2 and 1x1: weights per wave from L2) described first.  Only a -DL3C_DEV_PROBES build
+// (csrc/build.py --dev-probes, tools/conv_probe.py) honours the flags 0x100..0x800 in `epilogue`, which select development-probe
+// instantiations (parts of the kernel removed: WRONG results) / the v1 kernel for A/B measurements; the product library
+// rejects every epilogue bit it does not document.
 //
 // Replaces the cuDNN convolutions behind the reference's conv factory (pytorch_ext.py:57-61) for every 64-/192-input-
 // channel layer of the L3C stack: 3x3 (dilation 1, 2, 4), 5x5 stride 2, 1x1; epilogues: bias,
@@ -589,13 +591,19 @@ int launch_lds(ConvParams &p, hipStream_t stream) {
     const int64_t total = (int64_t)p.tiles_x * p.tiles_y * ((p.n_chunks_o + G::WN - 1) / G::WN) * p.B;
     L3C_REQUIRE(total < (1ll << 31), "grid too large");
     p.total_blocks = (int)total;
-    static bool attr_set = false;   // > 64 KB of dynamic LDS needs the opt-in
-    if (!attr_set) {
+    static bool attr_set[64] = {};   // > 64 KB of dynamic LDS needs the opt-in, once per device (and per instantiation: static)
+    int dev = 0;
+    {
+        const int rc = l3c::check_hip(hipGetDevice(&dev), "hipGetDevice");
+        if (rc != L3C_OK) return rc;
+    }
+    L3C_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    if (!attr_set[dev]) {
         const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_lds_kernel<KS, DIL, CK_, WN_, NW_, SLABS_>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES),
                                       "hipFuncSetAttribute");
         if (rc != L3C_OK) return rc;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     // Items per block: the kernel walks a contiguous range of items with cross-item prefetch (the next tile's first stage is
     // fetched during the current tile's last chunk, its epilogue stores overlap that fetch).  A fully persistent grid
@@ -633,17 +641,24 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
     if (rc != L3C_OK) return rc;
     L3C_REQUIRE(d->Cin % 16 == 0, "Cin must be a multiple of 16");
     hipStream_t s = l3c::as_stream(stream);
+#ifdef L3C_DEV_PROBES
+    const bool v1 = d->epilogue & 2048;
     if (d->KS == 3 && d->dilation == 1 && (d->epilogue & 0x300)) {
         const int dbg = (d->epilogue >> 8) & 3;
         return dbg == 1 ? launch<3, 1, 1, 16, 2, 1>(p, s) : dbg == 2 ? launch<3, 1, 1, 16, 2, 2>(p, s) : launch<3, 1, 1, 16, 2, 3>(p, s);
     }
-    if (d->KS == 3 && d->dilation == 1) return (d->epilogue & 2048) ? launch<3, 1, 1, 16, 2>(p, s) : launch_lds<3, 1>(p, s);
-    if (d->KS == 3 && d->dilation == 2) return (d->epilogue & 2048) ? launch<3, 1, 2, 16, 2>(p, s) : launch_lds<3, 2>(p, s);
-    if (d->KS == 3 && d->dilation == 4) return (d->epilogue & 2048) ? launch<3, 1, 4, 16, 2>(p, s) : launch_lds<3, 4>(p, s);
+    if (d->KS == 3 && v1) return d->dilation == 1 ? launch<3, 1, 1, 16, 2>(p, s) : d->dilation == 2 ? launch<3, 1, 2, 16, 2>(p, s) : launch<3, 1, 4, 16, 2>(p, s);
+#else
+    const bool v1 = false;
+    L3C_REQUIRE((d->epilogue & ~(L3C_EPI_RELU | L3C_EPI_RESIDUAL | L3C_EPI_PIXEL_SHUFFLE)) == 0, "unknown epilogue bits");
+#endif
+    if (d->KS == 3 && d->dilation == 1) return launch_lds<3, 1>(p, s);
+    if (d->KS == 3 && d->dilation == 2) return launch_lds<3, 2>(p, s);
+    if (d->KS == 3 && d->dilation == 4) return launch_lds<3, 4>(p, s);
     if (d->KS == 5) return launch<5, 2, 1, 16, 1>(p, s);
     // the 1x1 192->Kp layer: v3 with both output chunks of Kp = 120 in one block (patch staged once) measures 83 TFLOP/s vs
     // 78 for v1; with an odd number of chunks (Kp = 150) half a block would idle and v1 wins (64 vs 58)
-    if (!(d->epilogue & 2048) && d->Cin % 64 == 0 && ((d->Cout + 63) / 64) % 2 == 0) return launch_lds<1, 1, 64, 2>(p, s);
+    if (!v1 && d->Cin % 64 == 0 && ((d->Cout + 63) / 64) % 2 == 0) return launch_lds<1, 1, 64, 2>(p, s);
     return launch<1, 1, 1, 32, 2>(p, s);
 }
 

@@ -13,7 +13,8 @@ _CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU c
 _CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
 
 # Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
-# appends (kernel key, algorithmic FLOPs, start event, end event), the events being recorded on the launch stream.
+# appends (kernel key, algorithmic FLOPs, algorithmic HBM bytes, start event, end event), the events being recorded on the launch
+# stream.
 PROFILE = None
 PROFILE_DETAIL = bool(os.environ.get('L3C_PROFILE_DETAIL'))   # split the keys by layer shape (development)
 
@@ -79,7 +80,8 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         if PROFILE_DETAIL:
             key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '',
                                               ' shuffle' if pixel_shuffle else '')
-        PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, e0, e1))
+        nbytes = 4.0 * B * (H * W * layer.Cin + Ho * Wo * layer.Cout * (2 if residual is not None else 1))   # in + out (+ residual), once
+        PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1))
         return out
     call('l3c_conv_wino' if wino else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
     return out

@@ -1,0 +1,114 @@
+"""CPU baseline leg of bench.py (TEST / MEASUREMENT INFRASTRUCTURE ONLY, see oracle/__init__.py): the reference's CPU
+path timed on the host cores next to the GPU number (SURVEY.md section 8d "CPU reference timing").
+
+Protocol: `torch.set_num_threads(n)` for n in {all physical cores, 1}; one untimed warm-up forward on a small image
+(the reference discards its first image too, multiscale_tester.py:297); each n encodes ONE image; the best MPix/s is the
+baseline and the core count it was obtained with is reported.  The full-core run codes the bench's own image 0
+(768x512); the one-thread run codes the 384x256 top-left quarter of it, so that the leg stays within ~30 s of CPU work.
+
+kind 'reference': the unmodified reference (oracle/ref_import.py: /root/reference/src + its own torchac.cpp compiled by
+                  oracle/build_ref.py) -- only where /root/reference exists, i.e. in the build container;
+kind 'port':      oracle.bitcoding.encode, the restatement of the same path (torch-CPU convs, torch CDF tables, C range
+                  coder) -- what the GPU box can run.
+"""
+import os
+import time
+
+import torch
+
+
+def physical_cores():
+    """Distinct (package, core) pairs of /proc/cpuinfo; falls back to os.cpu_count()."""
+    try:
+        cores, phys, core = set(), None, None
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('physical id'):
+                    phys = line.split(':')[1].strip()
+                elif line.startswith('core id'):
+                    core = line.split(':')[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        n = len(cores)
+        if n:
+            try:
+                n = min(n, len(os.sched_getaffinity(0)))
+            except AttributeError:
+                pass
+            return n
+    except OSError:
+        pass
+    return os.cpu_count() or 1
+
+
+def _encode_port(img, sd):
+    from . import bitcoding as obc
+    with torch.no_grad():
+        return obc.encode(img, sd)
+
+
+def _reference_encoder(sd):
+    """-> callable(img) -> bytes running the UNMODIFIED reference's Bitcoding.encode (bitcoding.py:50-123)."""
+    import tempfile
+    from . import ref_import
+
+    def run(img):
+        with ref_import.reference_modules():
+            from fjcommon import config_parser as rcp, no_op
+            from blueprints.multiscale_blueprint import MultiscaleBlueprint
+            from bitcoding.bitcoding import Bitcoding
+            cfg, _ = rcp.parse('configs/ms/cr.cf')
+            bp = MultiscaleBlueprint(cfg)
+            bp.net.load_state_dict(sd, strict=True)
+            bp.set_eval()
+            bc = Bitcoding(bp, times=no_op.NoOp)
+            with torch.no_grad(), tempfile.TemporaryDirectory() as d:
+                p = os.path.join(d, 'x.l3c')
+                t0 = time.time()
+                bc.encode(img.clone(), p)
+                dt = time.time() - t0
+                with open(p, 'rb') as f:
+                    return f.read(), dt
+    return run
+
+
+def run(sd, img0, use_reference=None, one_thread=True):
+    """sd: L3C state dict; img0: (3,512,768) uint8 image 0 of the bench batch.  -> (cpu_baseline dict, bytes of the full image's
+    file from the all-cores run -- the bench compares its own file of the same image against them)."""
+    from . import net as onet, ref_import
+    if use_reference is None:
+        use_reference = ref_import.available()
+    kind = 'reference' if use_reference else 'port'
+    ref_enc = _reference_encoder(sd) if use_reference else None
+    n_all = physical_cores()
+    saved = torch.get_num_threads()
+    full = img0.unsqueeze(0).long()
+    quarter = full[:, :, :256, :384].contiguous()
+    runs, data_full = [], None
+    try:
+        for threads, img, label in ([(n_all, full, '768x512')] + ([(1, quarter, '384x256 (top-left quarter)')] if one_thread and n_all > 1 else [])):
+            torch.set_num_threads(threads)
+            with torch.no_grad():
+                onet.forward(torch.zeros(1, 3, 64, 96), sd)                      # warm-up (thread pool, allocator), discarded
+            if use_reference:
+                data, dt = ref_enc(img)
+            else:
+                t0 = time.time()
+                data = _encode_port(img, sd)
+                dt = time.time() - t0
+            px = img.shape[-1] * img.shape[-2]
+            runs.append({'threads': threads, 'image': label, 'seconds': round(dt, 2), 'mpix_per_s': round(px / 1e6 / dt, 5),
+                         'bytes': len(data)})
+            if img is full:
+                data_full = data
+    finally:
+        torch.set_num_threads(saved)
+    best = max(runs, key=lambda r: r['mpix_per_s'])
+    what = ("the unmodified reference's Bitcoding.encode (torch-CPU forward, torch CDF tables, its own torchac.cpp)" if use_reference
+            else 'oracle.bitcoding.encode: torch-CPU forward + torch CDF tables + C range coder')
+    return ({'value': best['mpix_per_s'], 'unit': 'MPix/s', 'cores': best['threads'], 'kind': kind,
+             'sample': 'one image per thread count, natural-like synthetic (image 0 of the bench batch), {}; best of {}'.format(
+                 what, ', '.join('{} thread(s) on {}: {} s'.format(r['threads'], r['image'], r['seconds']) for r in runs)),
+             'host_physical_cores': n_all, 'host_logical_cpus': os.cpu_count(), 'runs': runs}, data_full)

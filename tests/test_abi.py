@@ -93,6 +93,7 @@ def test_argument_validation_of_every_family_precedes_any_launch():
     assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 4' in err()
     d.Cout, d.epilogue = 64, 0x100
     assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'unknown epilogue bits' in err()
+    assert lib.l3c_conv_mfma(ctypes.byref(d), None) == -1 and 'unknown epilogue bits' in err()      # no probe kernels in the product
     d.epilogue = 0
     assert lib.l3c_conv_wino_set_tiles_per_block(2) == 0 and lib.l3c_conv_wino_set_tiles_per_block(0) == 2
     assert lib.l3c_conv_wino_packed_words(64, 64) == 16 * 64 * 64 and lib.l3c_conv_wino_packed_words(120, 64) == 16 * 128 * 64

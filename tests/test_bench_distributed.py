@@ -1,0 +1,47 @@
+"""bench.py's N > 1 path executed for real on the CPU: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2
+--stub-step` -- the driver's exact launch line with the hot path replaced by a sleep and RCCL by gloo.  What runs is the code
+the 8-GPU box will run: rank / world from the environment, process-group set-up, warm-up, barrier-bracketed timed region,
+all_reduce(MAX) of the time, all_reduce(SUM) of the work, ONE JSON line from rank 0, clean shutdown."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(nproc, steps=3, warmup=1):
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc), '--steps', str(steps),
+           '--warmup', str(warmup), '--stub-step']
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines                     # rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_world_size_2_under_torch_distributed_run():
+    r = _run(2)
+    assert r['n_gpus'] == 2 and r['steps'] == 3 and r['warmup'] == 1 and r['scaling'] == 'weak' and r['higher_is_better'] is True
+    # 9 items round-robin: rank 0 has 5, rank 1 has 4; rank 1 sleeps 20 ms per step, rank 0 10 ms: the slowest rank sets the time
+    assert r['ms_per_step'] >= 20.0
+    px = (5 + 4) * 512 * 768
+    assert abs(r['value'] - px * 3 / 1e6 / (r['ms_per_step'] * 3 / 1e3)) < 0.02 * r['value']
+    for k in ('metric', 'unit', 'vs_baseline', 'dtype', 'data', 'config'):
+        assert k in r
+
+
+def test_bench_world_size_1_under_torch_distributed_run():
+    r = _run(1, steps=2)
+    assert r['n_gpus'] == 1 and r['ms_per_step'] >= 10.0

@@ -76,15 +76,18 @@ def test_fused_intervals_equal_table_intervals(rgb, C, H, W):
 
 
 def test_channel_params_vs_reference_fixture(golden):
-    """CDFOut of the reference (logistic_mixture.py:134-141) on the reference's own P; fp32 tolerance 1e-5 (abs) on pi and
-    log_sigma, 1e-3 abs on the lambda-coupled RGB means (values up to ~500, 1 ulp = 3e-5)."""
+    """CDFOut of the reference (logistic_mixture.py:134-141) on the reference's own P: log_sigma and the uncoupled means bit-equal,
+    pi within 1e-6; the lambda-coupled RGB means mu + sigmoid(lambda) x (x up to 255, values up to ~500: 1 ulp = 3e-5) within
+    1e-4 absolute = 3 ulp (the sigmoid's expf differs in the last bit between the CPU and the GPU)."""
     from l3c_pytorch_amd import ops
     g = golden('net_32.npz')
     P0 = torch.from_numpy(g['P0']).cuda().permute(0, 2, 3, 1).contiguous()
     sym0 = torch.from_numpy(g['img'].astype(np.int16)).cuda()
     for c in range(3):
         pi, mu, ls = ops.dmll_channel_params(P0, sym0, 3, 10, True, c)
-        assert np.allclose(mu.cpu().numpy(), g['cdfout0_c%d/mu' % c], atol=1e-3, rtol=1e-6), c
+        err = np.abs(mu.cpu().numpy() - g['cdfout0_c%d/mu' % c]).max()
+        print('channel {}: max |mu - reference| = {:.3g} (max |mu| {:.1f})'.format(c, err, np.abs(g['cdfout0_c%d/mu' % c]).max()))
+        assert err <= (0 if c == 0 else 1e-4), (c, err)
         if c == 0:
             assert np.allclose(pi.cpu().numpy(), g['cdfout0_c0/pi'], atol=1e-6)
             assert (ls.cpu().numpy() == g['cdfout0_c0/log_sigma']).all()

@@ -70,12 +70,12 @@ def _err(got, ref):
     return float(d.max()), float(d.max() / ref.double().abs().max()), float(ref.abs().max())
 
 
-# tolerances: fp32 values of magnitude up to ~60 after ~40 conv layers, summed in a different order than
-# the CPU convolution (Winograd F(2x2,3x3) / MFMA k-blocks): 1e-5 RELATIVE to the tensor's largest magnitude (north_star's
-# 1e-5 read as relative: one fp32 ulp of a value of 32 is already 3.8e-6), and the absolute bound measured on this image x 2.
-TOL_REL = 1e-5
-TOL_ABS_F = 2e-5
-TOL_ABS_P = 1e-4
+# tolerances: the measured errors on this image (profiles/r02_parity_768x512.json: F 2.1e-6, P 4.4e-7
+# absolute; 1.9e-6 relative to the tensor's largest magnitude) x 2.5 -- all inside north_star's 1e-5.  The two sides sum ~40
+# layers of 576-term dot products in different orders (Winograd F(2x2,3x3) on MFMA k-blocks vs the CPU's direct convolution).
+TOL_REL = 5e-6
+TOL_ABS_F = 5e-6
+TOL_ABS_P = 2e-6
 
 
 def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c):

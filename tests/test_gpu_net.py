@@ -26,10 +26,24 @@ def _near_tie(x_prequant, levels, tol=5e-5):
     return (d[..., 1] - d[..., 0]) < tol
 
 
+# Tolerances of the network parity tests (measured on the MI355X: F within 2.1e-6, P within 4.4e-7 at
+# 768x512 -- tests/test_gpu_headline.py records them -- and no larger on the small images here): north_star's 1e-5, absolute.
+TOL_F = 1e-5
+TOL_P = 1e-5
+
+
+def _symbols_equal_up_to_near_ties(S, S_ref, bn_ref, levels):
+    """-> number of flipped symbols; every flip must sit where the REFERENCE's own pre-quantiser value is within 5e-5 of a
+    decision boundary (to_q sums 64 features: a 1e-5 difference in F moves it by a few 1e-5)."""
+    bad = S != S_ref
+    assert bad.sum() == 0 or _near_tie(bn_ref, levels)[bad].all()
+    return int(bad.sum())
+
+
 def test_forward_matches_reference_fixture(golden, blueprint, synthetic_l3c):
-    """config[0] (32x32): P and features within 1e-5-class fp32 tolerance of the reference CPU forward (abs 5e-5 on values
-    of magnitude ~1..30 after ~40 conv layers with a different summation order); symbols identical except provable
-    quantiser near-ties; per-scale bpsp within 1e-4 relative."""
+    """config[0] (32x32) against the reference's own CPU forward (tests/golden/net_32.npz): encoder features within 1e-5,
+    symbols identical except provable quantiser near-ties, P within 1e-5 -- through get_P on the reference's bottlenecks, so
+    that a flipped symbol cannot void the comparison -- and per-scale bpsp within 1e-4 relative (+ 16 bits per flipped symbol)."""
     cfg, sd = synthetic_l3c
     g = golden('net_32.npz')
     img = torch.from_numpy(g['img'].astype(np.float32)).cuda()
@@ -38,52 +52,62 @@ def test_forward_matches_reference_fixture(golden, blueprint, synthetic_l3c):
     assert torch.equal(out.S[0].cpu(), torch.from_numpy(g['S0'].astype(np.int64)))
     flips = 0
     for s in range(3):
-        bad = out.S[s + 1].cpu().numpy() != g['S%d' % (s + 1)]
-        flips += int(bad.sum())
-        assert bad.sum() == 0 or _near_tie(g['enc_bn%d' % s], levels)[bad].all(), s
+        flips += _symbols_equal_up_to_near_ties(out.S[s + 1].cpu().numpy(), g['S%d' % (s + 1)], g['enc_bn%d' % s], levels)
         Fe = out.raw.F_enc[s].cpu().permute(0, 3, 1, 2).numpy()
-        assert np.abs(Fe - g['enc_F%d' % s]).max() < 5e-5, (s, np.abs(Fe - g['enc_F%d' % s]).max())
-    if flips == 0:
-        for s in range(3):
-            P = out.P[s].cpu().numpy()
-            assert P.shape == g['P%d' % s].shape
-            err = np.abs(P - g['P%d' % s]).max()
-            assert err < 1e-4, (s, err)
-        loss = blueprint.get_loss(out)
-        got = np.array([float(b) for b in loss.nonrecursive_bpsps])
-        assert np.allclose(got, g['bpsp'], rtol=1e-4), (got, g['bpsp'])
+        err = np.abs(Fe - g['enc_F%d' % s]).max()
+        print('scale {}: max |F_enc - reference| = {:.3g}'.format(s, err))
+        assert err < TOL_F, (s, err)
+    f_prev = None
+    for s in (2, 1, 0):
+        P, f_prev = blueprint.net.get_P(s, torch.from_numpy(g['bn%d' % (s + 1)]).cuda(), f_prev)
+        assert P.shape == g['P%d' % s].shape
+        err = np.abs(P.cpu().numpy() - g['P%d' % s]).max()
+        print('scale {}: max |P - reference| = {:.3g}'.format(s, err))
+        assert err < TOL_P, (s, err)
+        if flips == 0:
+            assert torch.equal(P, out.P[s]), s            # and the forward pass computed exactly this
+    loss = blueprint.get_loss(out)
+    got = np.array([float(b) for b in loss.nonrecursive_bpsps])
+    assert np.allclose(got, g['bpsp'], rtol=1e-4, atol=16.0 * flips / img.numel()), (got, g['bpsp'], flips)
     assert out.L == [256, 25, 25, 25] and out.bn[0] is None
     for s in range(1, 4):
         assert torch.equal(out.bn[s].cpu(), torch.from_numpy(levels)[out.S[s].cpu()])
 
 
 def test_decoder_side_on_reference_bottlenecks(golden, blueprint):
-    """get_P fed with the REFERENCE's bn_q (so no quantiser flip can leak in): F and P within fp32 tolerance."""
+    """get_P fed with the REFERENCE's bn_q (so no quantiser flip can leak in): F and P within 1e-5."""
     g = golden('net_32.npz')
     f_prev = None
     for s in (2, 1, 0):
         bn = torch.from_numpy(g['bn%d' % (s + 1)]).cuda()
         P, f_prev = blueprint.net.get_P(s, bn, f_prev)
-        assert np.abs(f_prev.cpu().numpy() - g['dec_F%d' % s]).max() < 5e-5, s
-        assert np.abs(P.cpu().numpy() - g['P%d' % s]).max() < 1e-4, s
+        assert np.abs(f_prev.cpu().numpy() - g['dec_F%d' % s]).max() < TOL_F, s
+        assert np.abs(P.cpu().numpy() - g['P%d' % s]).max() < TOL_P, s
 
 
-@pytest.mark.parametrize('H,W', [(40, 56), (64, 96), (8, 8)])
+@pytest.mark.parametrize('H,W', [(40, 56), (64, 96), (8, 8), (104, 200)])
 def test_forward_vs_oracle_other_sizes(blueprint, synthetic_l3c, H, W):
+    """Other sizes against the oracle: the encoder chain (which never sees the symbols: enc.feed_F) from the forward pass, the
+    decoder chain and P through get_P on the ORACLE's bottlenecks; a flipped near-tie symbol is counted, never skipped."""
     from l3c_pytorch_amd.helpers import synthetic
     cfg, sd = synthetic_l3c
     img = synthetic.make_image(H, W, 5, 'natural').unsqueeze(0).float()
     with torch.no_grad():
         ref = onet.forward(img, sd)
+        bn_ref = [onet.conv(ref.F_enc[s], sd, 'nets.{}.enc.to_q.0'.format(s)).numpy() for s in range(3)]
     out = blueprint.forward(img.cuda())
     levels = sd['nets.0.enc.levels'].numpy()
+    flips = 0
     for s in range(3):
-        bad = (out.S[s + 1].cpu() != ref.S[s + 1]).numpy()
-        if bad.any():
-            pytest.skip('quantiser near-tie flipped a symbol at this size; downstream tensors are not comparable')
-        assert (out.raw.F_enc[s].cpu().permute(0, 3, 1, 2) - ref.F_enc[s]).abs().max() < 5e-5
-    for s in range(3):
-        assert (out.P[s].cpu() - ref.P[s]).abs().max() < 1e-4, s
+        flips += _symbols_equal_up_to_near_ties(out.S[s + 1].cpu().numpy(), ref.S[s + 1].numpy(), bn_ref[s], levels)
+        assert (out.raw.F_enc[s].cpu().permute(0, 3, 1, 2) - ref.F_enc[s]).abs().max() < TOL_F, s
+    f_prev = None
+    for s in (2, 1, 0):
+        P, f_prev = blueprint.net.get_P(s, ref.bn[s + 1].cuda(), f_prev)
+        assert (f_prev.cpu() - ref.F_dec[s]).abs().max() < TOL_F, s
+        assert (P.cpu() - ref.P[s]).abs().max() < TOL_P, s
+        if flips == 0:
+            assert torch.equal(P, out.P[s]), s
 
 
 def test_get_P_is_bit_identical_to_forward_and_batch_invariant(blueprint):

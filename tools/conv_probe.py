@@ -2,6 +2,10 @@
 """Development probe: time one conv configuration of the L3C stack (default: 3x3 64->64 at 256x384, batch 16).
 
     python tools/conv_probe.py [--ks 3 --dil 1 --stride 1 --cin 64 --cout 64 --B 16 --H 256 --W 384 --iters 20]
+
+--ablate N (probe bits 0x100..0x800 of `epilogue`: kernels with parts removed / the v1 kernel) needs the development library:
+    python l3c-pytorch_amd/csrc/build.py --dev-probes && L3C_LIB=l3c-pytorch_amd/csrc/libl3c_hip_devprobes.so python tools/conv_probe.py --ablate 256
+The product library rejects those bits.
 """
 import argparse
 import os
