@@ -192,11 +192,20 @@ class EncodedBatch(object):
 
 
 class Bitcoding(object):
-    def __init__(self, blueprint, times=None, compare_with_theory=False, coder_cus=0):
+    def __init__(self, blueprint, times=None, compare_with_theory=False, coder_cus=0, auto_recurse=0, file_writer=None):
         """coder_cus > 0: reserve that many compute units for the range coder.  `self.compute_stream` is then a stream
         confined to the remaining CUs -- run the network under `torch.cuda.stream(bc.compute_stream)` so the MFMA-bound
-        conv kernels and the latency-bound coder wavefronts never share a SIMD (they slow the coder down 2.3x)."""
+        conv kernels and the latency-bound coder wavefronts never share a SIMD (they slow the coder down 2.3x).
+        auto_recurse: RGB Shared baseline only -- how many times the coarsest scale is applied again (the reference evaluates it
+        with 3, multiscale_tester.py:50, and has no file coding for it, :187-188; here the `.l3c` layout simply carries one more
+        scale record per recursion, and the decoder counts the records).
+        file_writer: an AsyncFileWriter -- `encode` then hands the finished bytes to its worker threads instead of writing them
+        itself, `decode` waits for a pending write of the path it is asked to read."""
         self.blueprint = blueprint
+        self.auto_recurse = int(auto_recurse)
+        if self.auto_recurse and not blueprint.net.config_ms.rgb_bicubic_baseline:
+            raise ValueError('auto_recurse is only defined for the RGB baselines')
+        self.file_writer = file_writer
         self.compare_with_theory = compare_with_theory
         self.times = times if times is not None else _NullTimes()
         self._const = {}
@@ -240,11 +249,19 @@ class Bitcoding(object):
             self._const[key] = uniform_cdf_row(L).cuda()
         return self._const[key]
 
-    def iter_scale_dmll(self):
-        """coarsest -> finest: (scale, dmll, uniform)   (reference :163-169)"""
-        net, losses = self.blueprint.net, self.blueprint.losses
-        for scale in reversed(range(net.scales + 1)):
-            yield (scale, losses.loss_dmol_rgb if scale == 0 else losses.loss_dmol_n, scale == net.scales)
+    def n_predicted_scales(self):
+        """Scales coded with the network's prediction (the coarsest one on top of them is coded with the uniform prior)."""
+        return self.blueprint.net.scales + self.auto_recurse
+
+    def padding_factor(self):
+        return 2 ** self.n_predicted_scales()
+
+    def iter_scale_dmll(self, n_predicted=None):
+        """coarsest -> finest: (scale, dmll, uniform)   (reference :163-169; for the RGB baselines every scale is an RGB scale)"""
+        losses = self.blueprint.losses
+        n = self.n_predicted_scales() if n_predicted is None else n_predicted
+        for scale in reversed(range(n + 1)):
+            yield (scale, losses.loss_dmol_rgb if scale == 0 else losses.loss_dmol_n, scale == n)
 
     # ---- native batched API -----------------------------------------------------------------------------------------
 
@@ -253,11 +270,12 @@ class Bitcoding(object):
         turns P and the symbols into the coding intervals of all B*C streams.  Everything is enqueued on the current
         stream.  -> EncodedBatch whose `pending` list awaits `code()`."""
         net = self.blueprint.net
-        fac = 2 ** net.config_ms.num_scales
+        fac = self.padding_factor()
         B, _, H, W = imgs.shape
         assert H % fac == 0 and W % fac == 0, 'pad first: {}x{} not divisible by {}'.format(H, W, fac)
         if out is None:
-            out = net(imgs.to('cuda', torch.float32))
+            out = net(imgs.to('cuda', torch.float32), self.auto_recurse)
+        assert len(out.raw.P) == self.n_predicted_scales(), (len(out.raw.P), self.n_predicted_scales())
         raw = out.raw
         K = net.config_ms.prob.K
         enc = EncodedBatch(B, (H, W))
@@ -268,7 +286,7 @@ class Bitcoding(object):
                 iv = ops.intervals_from_table(self._uniform_row(dmll.L), sym.reshape(B * C, Hs * Ws), B * C, Hs * Ws,
                                               broadcast_row=True)
             else:
-                iv = ops.dmll_encode_intervals(raw.P[scale], sym, self._targets(dmll), C, K, dmll.rgb_scale)
+                iv = ops.dmll_encode_intervals(raw.P[scale], sym.contiguous(), self._targets(dmll), C, K, dmll.rgb_scale)
             enc.pending.append((C, Hs, Ws, iv))
         return enc
 
@@ -361,12 +379,16 @@ class Bitcoding(object):
         """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU,
         list of padding tuples)."""
         net = self.blueprint.net
+        rgb_net = bool(net.config_ms.rgb_bicubic_baseline)
         K = net.config_ms.prob.K
         B = len(files)
+        n_pred = count_scale_records(files[0]) - 1          # (every file of the batch must agree: their headers are compared below)
+        if n_pred < net.scales or (n_pred != net.scales and not (rgb_net and net.scales == 1)):
+            raise ValueError('invalid file: {} scale records, the model codes {}'.format(n_pred + 1, net.scales + 1))
         readers = [_Reader(f) for f in files]
         padding = [r.unpack('<4H') for r in readers]
         bn_prev, F_prev, sym = None, None, None
-        for scale, dmll, uniform in self.iter_scale_dmll():
+        for scale, dmll, uniform in self.iter_scale_dmll(n_pred):
             shapes = {r.unpack('<BHH') for r in readers}
             if len(shapes) != 1:
                 raise ValueError('decode_batch needs equally sized images, got shapes {}'.format(sorted(shapes)))
@@ -392,7 +414,7 @@ class Bitcoding(object):
                 sym = ops.ac_decode(self._uniform_row(dmll.L), buf, offs, lens, B * C, H * W, True,
                                     broadcast_row=True).reshape(B, C, H, W)
             else:
-                P, F_prev = net.get_P(scale, bn_prev, F_prev)
+                P, F_prev = net.get_P(scale, bn_prev, F_prev, n_scales_total=n_pred)
                 P = ops.as_pixel_major(P)
                 n_params = 4 if dmll.rgb_scale else 3
                 expect = (P.shape[-1] // (n_params * K), 2 * prev_hw[0], 2 * prev_hw[1])
@@ -406,6 +428,8 @@ class Bitcoding(object):
                 else:
                     sym = self._decode_z_scale(P, targets, payloads, B, C, K, H, W)
             bn_prev = ops.sym_to_bn(sym, dmll.bin_width, dmll.x_min)
+            if rgb_net and scale > 0:                  # BicubicDownsamplingEnc: the decoder is fed value - mean (net.py:72-80)
+                bn_prev = bn_prev - _rgb_mean_tensor(bn_prev.device)
         assert bn_prev is not None
         return bn_prev.round().long(), padding
 
@@ -501,7 +525,7 @@ class Bitcoding(object):
             print('Need to encode individual crops!')
             return self._encode_crops(list(auto_crop.iter_crops(img)), pout)
 
-        fac = 2 ** self.blueprint.net.config_ms.num_scales
+        fac = self.padding_factor()
         _, _, H, W = img.shape
         if H % fac != 0 or W % fac != 0:
             print('*** INFO: image shape ({}X{}) not divisible by {}, will pad.'.format(H, W, fac))
@@ -510,19 +534,18 @@ class Bitcoding(object):
             padding_tuple = (0, 0, 0, 0)
 
         with self.times.run('[-] encode forwardpass'):
-            out = self.blueprint.net(img.to('cuda', torch.float32))
+            out = self.blueprint.net(img.to('cuda', torch.float32), self.auto_recurse)
         loss_out = self.blueprint.get_loss(out) if self.compare_with_theory else None
         enc = self.encode_batch(img, out=out)
         data = enc.to_bytes([padding_tuple])[0]
-        with open(pout, 'wb') as fout:
-            fout.write(data)
+        self._write_file(pout, data)
 
         num_subpixels = int(np.prod(img.shape))
         actual_bpsp = len(data) * 8 / num_subpixels
         if self.compare_with_theory:
             per_scale = [int(n.sum().item()) * 8 / num_subpixels for _, _, _, _, n in enc.scales]
             tostr = lambda l: ' | '.join(map('{:.3f}'.format, l)) + ' => {:.3f}'.format(sum(l))   # noqa: E731
-            theory = [float(b) for b in loss_out.nonrecursive_bpsps]
+            theory = [float(b) for b in (loss_out.recursive_bpsps if self.auto_recurse else loss_out.nonrecursive_bpsps)]
             overhead = (sum(per_scale) / sum(theory) - 1) * 100
             print('Bitrates:\ntheory:  {}\nassumed: {} [{:.2f}%]\nactual:                                => {:.3f} '
                   '[{} bytes]'.format(tostr(theory), tostr(list(reversed(per_scale))), overhead, actual_bpsp, len(data)))
@@ -531,7 +554,7 @@ class Bitcoding(object):
     def _encode_crops(self, crops, pout):
         """The auto-crops of a large image (reference :63-71 codes them one after the other): crops of equal padded shape
         share a batch, all batches share ONE grouped coder launch (encode_many); part i goes to `pout`.part<i> as before."""
-        fac = 2 ** self.blueprint.net.config_ms.num_scales
+        fac = self.padding_factor()
         padded, pads, groups = [], [], {}
         for i, crop in enumerate(crops):
             assert not os.path.isfile(pout + part_suffix_helper.make_part_suffix(i))
@@ -552,19 +575,28 @@ class Bitcoding(object):
         files = EncodedBatch.many_to_bytes(encs, [[pads[i] for i in idxs] for idxs in order])
         for idxs, datas in zip(order, files):
             for i, data in zip(idxs, datas):
-                with open(pout + part_suffix_helper.make_part_suffix(i), 'wb') as fout:
-                    fout.write(data)
+                self._write_file(pout + part_suffix_helper.make_part_suffix(i), data)
                 sizes[i] = len(data)
         for i, crop in enumerate(crops):     # as the reference: bpsp of a part over its PADDED sub-pixels, weighted by its area
             comb.add(sizes[i] * 8 / int(np.prod(padded[i].shape)), int(np.prod(crop.shape[-2:])))
         return comb.get_bpsp()
 
+    def _write_file(self, path, data):
+        if self.file_writer is not None:
+            self.file_writer.submit(path, data)
+        else:
+            with open(path, 'wb') as fout:
+                fout.write(data)
+
+    def _read_file(self, path):
+        if self.file_writer is not None:
+            self.file_writer.wait(path)
+        with open(path, 'rb') as fin:
+            return fin.read()
+
     def _decode_parts(self, paths):
         """Part files of one image: parts of equal (padded) shape are decoded as one batch."""
-        datas = []
-        for p in paths:
-            with open(p, 'rb') as fin:
-                datas.append(fin.read())
+        datas = [self._read_file(p) for p in paths]
         groups = {}
         for i, d in enumerate(datas):
             groups.setdefault(d[8:13], []).append(i)      # the coarsest scale's header (C, H, W) identifies the padded shape
@@ -578,16 +610,79 @@ class Bitcoding(object):
 
     def decode(self, pin, _recurse_part=True):
         """-> decoded image, 1CHW long (on the GPU)."""
+        if self.file_writer is not None:
+            self.file_writer.wait(pin)                 # (a part suffix is resolved below: every part is waited for when read)
         if _recurse_part and part_suffix_helper.contains_part_suffix(pin):
             parts = self._decode_parts(list(part_suffix_helper.iter_part_suffixes(pin)))
             print('Stitching {} parts...'.format(len(parts)))
             return auto_crop.stitch(parts)
-        with open(pin, 'rb') as fin:
-            data = fin.read()
+        data = self._read_file(pin)
         out, padding = self.decode_batch([data])
         if any(padding[0]):
             out = pad.undo_pad(out, *padding[0])
         return out
+
+
+_RGB_MEAN_T = {}
+
+
+def _rgb_mean_tensor(device):
+    """(1,3,1,1) fp32 tensor of (0.4488, 0.4371, 0.4040) * 255 -- the same fp32 values the encoder side subtracts (ops.rgb_mean)."""
+    key = str(device)
+    if key not in _RGB_MEAN_T:
+        _RGB_MEAN_T[key] = torch.tensor([float(v) for v in ops.rgb_mean()], dtype=torch.float32, device=device).reshape(1, 3, 1, 1)
+    return _RGB_MEAN_T[key]
+
+
+def count_scale_records(data):
+    """Number of scale records of a `.l3c` byte string (u8 C, u16 H, u16 W, C x (u32 n + payload), magic); ValueError if the
+    framing is broken.  An L3C file has num_scales + 1 of them; an RGB Shared file one more per recursion."""
+    r = _Reader(data)
+    r.take(8)
+    n = 0
+    while r.p < len(data):
+        C, _, _ = r.unpack('<BHH')
+        for _ in range(C):
+            nb, = r.unpack('<I')
+            r.take(nb)
+        if r.take(4) != _MAGIC_VALUE_SEP:
+            raise ValueError('invalid file: scale separator missing')
+        n += 1
+    if n < 2:
+        raise ValueError('invalid file: {} scale record(s)'.format(n))
+    return n
+
+
+class AsyncFileWriter(object):
+    """Writes finished `.l3c` byte strings on worker threads (file output is not part of the hot path: reference bitcoding.py:
+    326-375 writes from the coding loop).  `wait(path)` blocks until a pending write of `path` is on disk; `close()` drains."""
+
+    def __init__(self, n_threads=2):
+        import concurrent.futures
+        self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=n_threads, thread_name_prefix='l3c-write')
+        self._pending = {}
+
+    @staticmethod
+    def _write(path, data):
+        with open(path, 'wb') as f:
+            f.write(data)
+
+    def submit(self, path, data):
+        self.wait(path)
+        self._pending[path] = self._pool.submit(self._write, path, data)
+
+    def wait(self, path=None):
+        for p in ([path] if path is not None else list(self._pending)):
+            fut = self._pending.pop(p, None)
+            if fut is not None:
+                fut.result()
+
+    def pending(self):
+        return len(self._pending)
+
+    def close(self):
+        self.wait()
+        self._pool.shutdown()
 
 
 class _Reader(object):

@@ -100,7 +100,8 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
 
 // Development probes (csrc/build.py --wino-probe N; results are WRONG, only the time means something): bit 0 no patch loads,
 // 1 no patch stores to LDS, 2 no input transform, 3 no weight loads inside the loop, 4 no chunk barrier, 5 no output stores,
-// 6 (correct results) the patch fetch at the end of the chunk.  Never defined in the product build.
+// (tried and dropped: the patch fetch behind the chunk's weight loads instead of ahead of them -- no difference).  Never defined
+// in the product build.
 #ifndef L3C_WINO_PROBE
 #define L3C_WINO_PROBE 0
 #endif
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 1);
             if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_cols(0);
             L3C_WINO_MFMA(q + 1, 1, A1, B1)
-            if (pp == 0 && !(L3C_WINO_PROBE & 64)) fetch_patch_piece(par, 0);   // patch g + 4 into the set just stored
+            if (pp == 0) fetch_patch_piece(par, 0);   // patch g + 4 into the set just stored
             if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_rows(0);
             if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_write(v_next, 0);
             L3C_WINO_MFMA(q, 2, A0, B0)
@@ -382,43 +383,35 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_rows(1);
             if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_cols(1);
             L3C_WINO_MFMA(q + 1, 2, A1, B1)
-            if (pp == 0 && !(L3C_WINO_PROBE & 64)) fetch_patch_piece(par, 1);
+            if (pp == 0) fetch_patch_piece(par, 1);
             if (pp == 0 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 2);
-            if (pp == 1 && !(L3C_WINO_PROBE & 64)) pf_advance();       // the prefetch pointer moves on (into the next tile: new column offsets)
+            if (pp == 1) pf_advance();       // the prefetch pointer moves on (into the next tile: new column offsets)
             if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_write(v_next, 1);
             L3C_WINO_MFMA(q, 3, A0, B0)
             if constexpr (!(L3C_WINO_PROBE & 8)) fetch_b(cc_b, q);
             L3C_WINO_MFMA(q + 1, 3, A1, B1)
             if constexpr (!(L3C_WINO_PROBE & 8)) fetch_b(cc_b, q + 1);
-            if constexpr ((L3C_WINO_PROBE & 64) != 0) {   // variant (correct results): the patch fetch BEHIND the chunk's weight loads
-                if (pp == 3) {
-                    fetch_patch_piece(par, 0);
-                    fetch_patch_piece(par, 1);
-                    pf_advance();
-                }
-            }
         }
 #undef L3C_WINO_MFMA
     };
 
     constexpr int S = SHUFFLE ? 2 : 1;
     constexpr int OOB = 0x7ffffff0;   // a byte offset beyond every buffer: the access is dropped by the range check
-    // Output / residual addressing: ONE uniform descriptor per image (a descriptor with a per-lane field would cost a
-    // waterfall loop per access), one per-lane byte offset, and a scalar offset per group of 8 pixels that carries the tile
-    // origin.  A lane whose channels do not exist, or -- in a tile that sticks out of the image -- whose pixel does not exist,
+    // Output / residual addressing: ONE uniform descriptor at the block's first output row (a descriptor with a per-lane field
+    // would cost a waterfall loop per access; based at the row, not at the image: the 32-bit offsets then span a few rows,
+    // whatever the image size -- the 192-channel concat of a 2000 x 1500 image is 2.3 GB), one per-lane byte offset, and a
+    // scalar offset per group of 8 pixels that carries the tile origin.  A lane whose channels do not exist, or -- in a tile that sticks out of the image -- whose pixel does not exist,
     // gets the out-of-range offset instead.  Pixel shuffle (dil = 1): conv pixel (oy, ox), channel co -> pixel
     // (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2 of a 2H x 2W image: the same walk with doubled strides, the
     // sub-pixel in the lane offset.
     const int col_b = S * dil * p.out_cstride * 4, row_b = S * dil * (S * p.W) * p.out_cstride * 4;   // one conv pixel / row on
     const int rcol_b = dil * p.res_cstride * 4, rrow_b = dil * p.W * p.res_cstride * 4;
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.out + (size_t)b * (S * p.H) * (S * p.W) * p.out_cstride + p.out_coff + (SHUFFLE ? chunk_o * 16 : chunk_o * 64), 0,
-        (S * p.H) * (S * p.W) * p.out_cstride * 4, 0x00020000);
-    const int o_row0 = (S * (py + dil * sy0) * (S * p.W) + S * px) * p.out_cstride * 4;   // + tile: S dil sx0 pixels further
+        p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * px) * p.out_cstride + p.out_coff +
+            (SHUFFLE ? chunk_o * 16 : chunk_o * 64), 0, OOB, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(RES ? p.res + (size_t)b * p.H * p.W * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias), 0,
-        RES ? p.H * p.W * p.res_cstride * 4 : 0, 0x00020000);
-    const int r_row0 = ((py + dil * sy0) * p.W + px) * p.res_cstride * 4;
+        const_cast<float *>(RES ? p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px) * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias),
+        0, RES ? OOB : 0, 0x00020000);
     const bool rows_in = py + dil * (sy0 + WT_H - 1) < p.H;
 
     for (int t = 0; t < n_t; ++t) {
@@ -496,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         else hand_over(std::integral_constant<int, 1>{});
         f32x4 resv[8];
         if constexpr (RES) {   // the residual values in the store layout (the accumulators are dead: they take their registers)
-            const int r_tile = r_row0 + sx0 * rcol_b;
+            const int r_tile = sx0 * rcol_b;
 #pragma unroll
             for (int k = 0; k < 8; ++k)
                 resv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
@@ -551,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         // the data registers of a 16-byte buffer store that was issued just before (register soffset: the compiler sees no
         // hazard and inserts no wait states) can overtake the store's read of its last dwords -- measured: the 4th dword
         // of the last lanes of each 16-lane group came out as the NEXT store's value.
-        const int o_tile = o_row0 + sx0 * col_b;
+        const int o_tile = sx0 * col_b;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < ((L3C_WINO_PROBE & 32) ? 1 : 8); ++k)
@@ -679,10 +672,12 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
     p.groups_x = (p.tiles_x + tpb - 1) / tpb;
     const int64_t total = rows * p.groups_x;
     L3C_REQUIRE(total < (1ll << 31), "grid too large");
-    // 32-bit byte offsets inside one image (buffer addressing): input, output (pixel shuffle: 2H x 2W) and residual
+    // 32-bit byte offsets (buffer addressing): inside one image of the input; inside the 8 x dilation rows of a block's output /
+    // residual tile row
     const int64_t S2 = (d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? 4 : 1;
-    L3C_REQUIRE((int64_t)p.H * p.W * p.in_cstride * 4 < 0x7ffffff0ll && S2 * p.H * p.W * p.out_cstride * 4 < 0x7ffffff0ll &&
-                (int64_t)p.H * p.W * p.res_cstride * 4 < 0x7ffffff0ll, "one image of a tensor must stay below 2 GB");
+    L3C_REQUIRE((int64_t)p.H * p.W * p.in_cstride * 4 < 0x7ffffff0ll, "one image of the input must stay below 2 GB");
+    L3C_REQUIRE(S2 * 8 * p.dil * (p.W + 64 * p.dil) * p.out_cstride * 4 < 0x7ffffff0ll && 8ll * p.dil * (p.W + 64 * p.dil) * p.res_cstride * 4 < 0x7ffffff0ll,
+                "image too wide for 32-bit offsets inside a tile row");
     p.total_blocks = (int)total;
     p.div_groups = wino_div((unsigned)(p.groups_x * p.tiles_y));
     p.div_groups_x = wino_div((unsigned)p.groups_x);

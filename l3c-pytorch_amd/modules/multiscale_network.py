@@ -292,18 +292,28 @@ class MultiscaleNetwork(nn.Module):
             out.append(EncOut(bn, bn, sym.long(), 256, None), P.permute(0, 3, 1, 2))
         return out
 
-    def get_P(self, scale, bn_q, dec_F_prev=None):
+    def get_P(self, scale, bn_q, dec_F_prev=None, n_scales_total=None):
         """Decoder-side step (reference :308-322): (P_scale, F_scale) from the quantised bottleneck of scale+1 and the
-        coarser decoder's features.  Tensors use the reference's logical NCHW shapes (F / P are permuted views)."""
-        assert 0 <= scale < self.config_ms.num_scales, 'Out of range: {}'.format(scale)
+        coarser decoder's features.  Tensors use the reference's logical NCHW shapes (F / P are permuted views).
+        n_scales_total (RGB baselines with auto_recurse only): number of predicted scales of the forward pass this step belongs
+        to -- scales >= num_scales are the recursive applications of the last network, which take no fused features."""
+        n_total = self.config_ms.num_scales if n_scales_total is None else n_scales_total
+        assert 0 <= scale < n_total, 'Out of range: {}'.format(scale)
+        assert n_total == self.config_ms.num_scales or self._rgb, 'recursion is only defined for the RGB baselines'
         _lib.require_gpu()
         pk = self._prepare()
         bn_q = bn_q.to('cuda', torch.float32).contiguous()
+        net = min(scale, self.scales - 1)
+        if self._rgb:      # same rule as _forward_rgb: no fusion for recursive scales, nor for the coarsest proper one
+            forward_scales = list(range(self.scales)) + [-1] * (n_total - self.scales)
+            s = forward_scales[scale]
+            if not self._fuse_feat or s == -1 or s == max(forward_scales):
+                dec_F_prev = None
         fuse = None
         if dec_F_prev is not None:
             fuse = dec_F_prev.permute(0, 2, 3, 1).contiguous()
-        F = self._decoder(bn_q, fuse, scale, pk)
-        P = self._prob(F, scale, pk)
+        F = self._decoder(bn_q, fuse, net, pk)
+        P = self._prob(F, net, pk)
         return P.permute(0, 3, 1, 2), F.permute(0, 3, 1, 2)
 
     @staticmethod

@@ -17,7 +17,7 @@ from PIL import Image
 
 from .. import auto_crop
 from ..bitcoding import part_suffix_helper
-from ..bitcoding.bitcoding import Bitcoding
+from ..bitcoding.bitcoding import AsyncFileWriter, Bitcoding
 from ..blueprints.multiscale_blueprint import MultiscaleBlueprint
 from ..helpers import config_parser, paths
 
@@ -188,12 +188,15 @@ class MultiscaleTester(object):
         self.restore_itr, ckpt_p = paths.get_ckpt_for_itr(paths.get_ckpts_dir(experiment_dir), restore_itr)
         paths.restore({'net': self.blueprint.net}, ckpt_p, strict=True)
         self.times = StackTimeLogger()
-        self.bc = Bitcoding(self.blueprint, times=self.times if getattr(flags, 'write_to_files', None) else None,
-                            compare_with_theory=bool(getattr(flags, 'compare_theory', False)))
         self.recursive = self._parse_recursive_flag(getattr(flags, 'recursive', '0'), self.config_ms)
-        if self.recursive and getattr(flags, 'write_to_files', None):
-            raise NotImplementedError('--write_to_files not implemented for --recursive (same as the reference, :187-188)')
+        # --write_to_files works for --recursive too (the reference raises NotImplementedError, :187-188): the `.l3c` layout carries
+        # one more scale record per recursion.  Finished files are written by worker threads.
+        self.file_writer = AsyncFileWriter() if getattr(flags, 'write_to_files', None) else None
+        self.bc = Bitcoding(self.blueprint, times=self.times if getattr(flags, 'write_to_files', None) else None,
+                            compare_with_theory=bool(getattr(flags, 'compare_theory', False)), auto_recurse=self.recursive,
+                            file_writer=self.file_writer)
         self.max_batch = int(getattr(flags, 'batch', None) or 8)
+        self.io_threads = int(getattr(flags, 'io_threads', None) or 4)
         exp_name = os.path.basename(experiment_dir)
         self.out_dir = os.path.join(flags.log_dir.rstrip(os.path.sep) + '_test', exp_name)
         self.test_output_cache = TestOutputCache(self.out_dir)
@@ -236,6 +239,26 @@ class MultiscaleTester(object):
             return None
         self.test_output_cache[test_id] = result
         return result
+
+    def _iter_images(self, ps):
+        """(index, path, uint8 CHW tensor) in order; the files are read and decoded by `io_threads` worker threads a few images
+        ahead of the consumer (PIL releases the GIL while it inflates a PNG: reference images_loader.py:91-129 decodes on the
+        main thread, one image at a time)."""
+        import concurrent.futures
+        ahead = 2 * self.io_threads
+        with concurrent.futures.ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix='l3c-read') as pool:
+            futs = collections.deque()
+            it = iter(enumerate(ps))
+            for i, p in it:
+                futs.append((i, p, pool.submit(self._load_uint8, p)))
+                if len(futs) >= ahead:
+                    break
+            while futs:
+                i, p, f = futs.popleft()
+                nxt = next(it, None)
+                if nxt is not None:
+                    futs.append((nxt[0], nxt[1], pool.submit(self._load_uint8, nxt[1])))
+                yield i, p, f.result()
 
     def _load_uint8(self, img_p):
         img = Image.open(img_p)
@@ -296,8 +319,8 @@ class MultiscaleTester(object):
         test_result = TestResult('bpsp recursive' if self.recursive else 'bpsp')
         # every auto-crop of every image, grouped by padded shape so that equal shapes share one forward
         items, groups = [], collections.defaultdict(list)
-        for i, img_p in enumerate(testset.ps):
-            raw = self._load_uint8(img_p).unsqueeze(0)
+        for i, img_p, raw in self._iter_images(testset.ps):
+            raw = raw.unsqueeze(0)
             for crop in auto_crop.iter_crops(raw):
                 n_sub = int(np.prod(crop.shape))
                 padded = MultiscaleBlueprint.pad(crop, self._padding_fac())
@@ -327,13 +350,15 @@ class MultiscaleTester(object):
         test_result = TestResult('bpsp')
         out_dir = self.flags.write_to_files
         os.makedirs(out_dir, exist_ok=True)
-        for i, img_p in enumerate(testset.ps):
+        for i, img_p, raw in self._iter_images(testset.ps):       # the next images are decoded while this one is on the GPU
             filename = os.path.splitext(os.path.basename(img_p))[0]
             print('***', filename)
-            img = self._load_uint8(img_p).unsqueeze(0).long()
+            img = raw.unsqueeze(0).long()
             with self.times.skip(i == 0):
                 test_result[filename] = self._write_to_file(img, os.path.join(out_dir, filename + _FILE_EXT))
             print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+        if self.file_writer is not None:
+            self.file_writer.wait()
         return test_result
 
     def _write_to_file(self, img, out_p):
@@ -343,6 +368,9 @@ class MultiscaleTester(object):
                 os.remove(stale)
         with self.times.run('=== bc.encode'):
             bpsp = self.bc.encode(img, pout=out_p)
+        if self.file_writer is not None:       # the round trip below reads the file back: here the write has to be waited for
+            with self.times.run('=== file write (worker thread, waited for)'):
+                self.file_writer.wait()
         out_p_part = out_p + part_suffix_helper.make_part_suffix(0)
         if not os.path.isfile(out_p) and os.path.isfile(out_p_part):
             out_p = out_p_part

@@ -1,10 +1,11 @@
 """CPU baseline leg of bench.py (TEST / MEASUREMENT INFRASTRUCTURE ONLY, see oracle/__init__.py): the reference's CPU
 path timed on the host cores next to the GPU number (SURVEY.md section 8d "CPU reference timing").
 
-Protocol: `torch.set_num_threads(n)` for n in {all physical cores, 1}; one untimed warm-up forward on a small image
-(the reference discards its first image too, multiscale_tester.py:297); each n encodes ONE image; the best MPix/s is the
-baseline and the core count it was obtained with is reported.  The full-core run codes the bench's own image 0
-(768x512); the one-thread run codes the 384x256 top-left quarter of it, so that the leg stays within ~30 s of CPU work.
+Protocol: `torch.set_num_threads(n)` for n in {all physical cores, 16 (when the box has more: torch's CPU convolutions stop
+scaling long before 128 threads), 1}; one untimed warm-up forward on a small image (the reference discards its first image
+too, multiscale_tester.py:297); each n encodes ONE image; the best MPix/s is the baseline and the core count it was obtained
+with is reported.  The multi-thread runs code the bench's own image 0 (768x512); the one-thread run codes the 384x256 top-
+left quarter of it, so that the leg stays within ~30 s of CPU work.
 
 kind 'reference': the unmodified reference (oracle/ref_import.py: /root/reference/src + its own torchac.cpp compiled by
                   oracle/build_ref.py) -- only where /root/reference exists, i.e. in the build container;
@@ -88,7 +89,12 @@ def run(sd, img0, use_reference=None, one_thread=True):
     quarter = full[:, :, :256, :384].contiguous()
     runs, data_full = [], None
     try:
-        for threads, img, label in ([(n_all, full, '768x512')] + ([(1, quarter, '384x256 (top-left quarter)')] if one_thread and n_all > 1 else [])):
+        plan = [(n_all, full, '768x512')]
+        if n_all > 16:
+            plan.append((16, full, '768x512'))
+        if one_thread and n_all > 1:
+            plan.append((1, quarter, '384x256 (top-left quarter)'))
+        for threads, img, label in plan:
             torch.set_num_threads(threads)
             with torch.no_grad():
                 onet.forward(torch.zeros(1, 3, 64, 96), sd)                      # warm-up (thread pool, allocator), discarded
@@ -101,7 +107,7 @@ def run(sd, img0, use_reference=None, one_thread=True):
             px = img.shape[-1] * img.shape[-2]
             runs.append({'threads': threads, 'image': label, 'seconds': round(dt, 2), 'mpix_per_s': round(px / 1e6 / dt, 5),
                          'bytes': len(data)})
-            if img is full:
+            if img is full and data_full is None:
                 data_full = data
     finally:
         torch.set_num_threads(saved)

@@ -47,6 +47,7 @@ def main(argv=None):
     p.add_argument('--time_report', type=str, metavar='TIME_REPORT_PATH')
     p.add_argument('--sort_output', '-s', choices=['testset', 'exp', 'itr', 'res'], default='testset')
     p.add_argument('--batch', type=int, default=8, help='crops of equal padded shape evaluated per forward')
+    p.add_argument('--io_threads', type=int, default=4, help='worker threads that read and decode the image files ahead of the GPU')
     flags = p.parse_args(argv)
 
     if flags.compare_theory and not flags.write_to_files:

@@ -138,3 +138,59 @@ def test_rgb_decode_pipeline_schedule():
                         assert when[(c, j - 1)] == t - 1      # a stream's state is carried from one step to the next
                     if c:
                         assert when[(c - 1, j)] <= t - D
+
+
+def test_count_scale_records_and_async_writer(tmp_path):
+    """the `.l3c` framing walk that tells the decoder how many scales a file holds (L3C: 4; RGB Shared: one more per recursion),
+    and the worker-thread file writer: wait(path) makes a pending write visible, overwriting waits for the previous write."""
+    import struct
+    from l3c_pytorch_amd.bitcoding.bitcoding import AsyncFileWriter, count_scale_records, _MAGIC_VALUE_SEP
+
+    def record(C, H, W, payloads):
+        return struct.pack('<BHH', C, H, W) + b''.join(struct.pack('<I', len(p)) + p for p in payloads) + _MAGIC_VALUE_SEP
+
+    head = struct.pack('<4H', 0, 0, 0, 0)
+    f4 = head + record(5, 1, 1, [b'a'] * 5) + record(5, 2, 2, [b'bb'] * 5) + record(5, 4, 4, [b''] * 5) + record(3, 8, 8, [b'xyz'] * 3)
+    assert count_scale_records(f4) == 4
+    f5 = head + b''.join(record(3, 1 << i, 1 << i, [bytes(i)] * 3) for i in range(5))
+    assert count_scale_records(f5) == 5
+    import pytest
+    with pytest.raises(ValueError):
+        count_scale_records(f4[:-2])                      # truncated
+    with pytest.raises(ValueError):
+        count_scale_records(f4[:-4] + b'\\0\\0\\0\\0')        # separator missing
+    with pytest.raises(ValueError):
+        count_scale_records(head + record(5, 1, 1, [b'a'] * 5))
+    w = AsyncFileWriter(n_threads=2)
+    paths = [str(tmp_path / 'f{}.bin'.format(i)) for i in range(20)]
+    for i, p in enumerate(paths):
+        w.submit(p, bytes([i]) * 100000)
+    w.submit(paths[3], b'second')                         # same path again: ordered after the first write
+    w.wait(paths[3])
+    assert open(paths[3], 'rb').read() == b'second'
+    w.close()
+    assert w.pending() == 0
+    for i, p in enumerate(paths):
+        if i != 3:
+            assert open(p, 'rb').read() == bytes([i]) * 100000
+
+
+def test_tester_image_prefetch_keeps_order(tmp_path):
+    """MultiscaleTester._iter_images: files decoded on worker threads ahead of the consumer, yielded strictly in order."""
+    import numpy as np
+    from PIL import Image
+    from l3c_pytorch_amd.test.multiscale_tester import MultiscaleTester
+    ps = []
+    for i in range(11):
+        p = str(tmp_path / '{:02d}.png'.format(i))
+        Image.fromarray(np.full((5 + i, 7, 3), i, dtype=np.uint8)).save(p)
+        ps.append(p)
+
+    class Flags(object):
+        crop = None
+    t = MultiscaleTester.__new__(MultiscaleTester)           # only the loader is exercised: no checkpoint, no GPU
+    t.flags, t.io_threads = Flags(), 3
+    got = list(t._iter_images(ps))
+    assert [i for i, _, _ in got] == list(range(11)) and [p for _, p, _ in got] == ps
+    for i, _, img in got:
+        assert tuple(img.shape) == (3, 5 + i, 7) and int(img.max()) == i
