@@ -380,8 +380,9 @@ class Bitcoding(object):
         list of padding tuples).
         (Tried and dropped [measured, batch 128]: cutting the batch into 2-4 parts that run the same chain on streams of their
         own, so that one part's latency-bound decoder launches would leave room for another part's convolutions and tables:
-        0.71 s became 2.98 / 1.01 / 1.10 s -- with the runtime's four hardware queues the parts' main and side streams alias
-        and serialise each other's long decoder launches.)"""
+        0.70 s became 0.87 - 2.98 s with the runtime's four hardware queues (the parts' main and side streams alias and serialise
+        each other's long decoder launches) and 0.76 / 1.00 s with 8 or 16 queues -- a decoder wavefront that shares its SIMD
+        with MFMA wavefronts runs 2.3x slower, which costs more than the overlap saves; profiles/r02_decode_parts_tried.log.)"""
         net = self.blueprint.net
         rgb_net = bool(net.config_ms.rgb_bicubic_baseline)
         K = net.config_ms.prob.K
