@@ -40,12 +40,29 @@ def _fetch_stream(out, nbytes, s=0):
     return out[s, :n].cpu().numpy().tobytes()
 
 
+def _check_symbols(sym, Lp):
+    """The coder indexes table rows with the symbols: out-of-range ones would read past a row (the reference does, silently)."""
+    if sym.numel() and (int(sym.min()) < 0 or int(sym.max()) > Lp - 2):
+        raise ValueError('symbols must lie in [0, {}], got [{}, {}]'.format(Lp - 2, int(sym.min()), int(sym.max())))
+
+
+def _check_intervals(iv):
+    """Encoder precondition on a USER table (torchac.cpp:174-207 divides the range by c_high - c_low): every coded symbol
+    needs c_high > c_low.  An empty interval makes the reference emit an undecodable stream; here it could additionally emit
+    more than the 16 bits per symbol the output rows are sized for -- refuse it.  (Word = c_low | (c_high - 1) << 16.)"""
+    lo, hi = iv & 0xFFFF, (iv >> 16) & 0xFFFF
+    if bool((hi < lo).any()):
+        raise ValueError('cdf is not increasing at a coded symbol (c_high <= c_low): the stream would not be decodable')
+
+
 def encode_cdf(cdf, sym):
     N, Lp = _check_cdf(cdf)
     sym = _dev(sym.reshape(-1), torch.int16)
     if sym.numel() != N:
         raise RuntimeError('cdf has {} rows but {} symbols were given'.format(N, sym.numel()))
+    _check_symbols(sym, Lp)
     iv = ops.intervals_from_table(_dev(cdf).reshape(N, Lp), sym.reshape(1, N), 1, N)
+    _check_intervals(iv)
     out, nbytes = ops.ac_encode(iv, 1, N)
     return _fetch_stream(out, nbytes)
 
@@ -78,7 +95,9 @@ def encode_logistic_mixture(targets, means, log_scales, logit_probs_softmax, sym
     N = _check_mixture(targets, means, log_scales, logit_probs_softmax)
     table, _ = _mixture_table(targets, means, log_scales, logit_probs_softmax)
     sym = _dev(sym.reshape(-1), torch.int16)
+    _check_symbols(sym, table.shape[-1])
     iv = ops.intervals_from_table(table.reshape(N, -1), sym.reshape(1, N), 1, N)
+    _check_intervals(iv)
     out, nbytes = ops.ac_encode(iv, 1, N)
     return _fetch_stream(out, nbytes)
 

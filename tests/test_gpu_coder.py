@@ -192,3 +192,22 @@ def test_torchac_facade_roundtrip_and_errors(golden):
         torchac.encode_logistic_mixture(torch.zeros(26).cuda(), torch.zeros(1, 10, 4, 4), torch.zeros(1, 10, 4, 4),
                                         torch.zeros(1, 10, 4, 4), torch.zeros(16, dtype=torch.int16))
     assert torchac.CUDA_SUPPORTED and not torchac.CPU_SUPPORTED
+
+
+def test_torchac_facade_refuses_tables_and_symbols_that_would_overrun():
+    """encode_cdf on a user table: symbols outside [0, Lp-2] and empty intervals at a coded symbol are refused (the reference
+    reads past the row / emits an undecodable stream; the HIP coder's output rows are sized for <= 16 bits per symbol)."""
+    from l3c_pytorch_amd import torchac
+    tab = torch.arange(0, 26 * 100, 100, dtype=torch.int32).to(torch.int16).reshape(1, 1, 1, 26).repeat(1, 2, 3, 1)
+    sym = torch.tensor([0, 3, 24, 7, 1, 2], dtype=torch.int16)
+    data = torchac.encode_cdf(tab, sym)
+    assert torch.equal(torchac.decode_cdf(tab, data), sym)
+    with pytest.raises(ValueError, match='symbols must lie'):
+        torchac.encode_cdf(tab, torch.tensor([0, 3, 25, 7, 1, 2], dtype=torch.int16))
+    with pytest.raises(ValueError, match='symbols must lie'):
+        torchac.encode_cdf(tab, torch.tensor([0, -1, 2, 7, 1, 2], dtype=torch.int16))
+    bad = tab.clone()
+    bad[0, 0, 1, 4] = bad[0, 0, 1, 3]                  # row 1: entries 3 and 4 equal -> symbol 3 has an empty interval
+    assert torchac.encode_cdf(bad, torch.tensor([0, 2, 24, 7, 1, 2], dtype=torch.int16))       # not coded there: fine
+    with pytest.raises(ValueError, match='not increasing'):
+        torchac.encode_cdf(bad, sym)                   # symbol 3 at row 1
