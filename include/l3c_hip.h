@@ -251,6 +251,15 @@ int64_t l3c_conv_wino_packed_words(int Cout, int Cin);
 int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
 int l3c_conv_wino(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 int l3c_conv_wino_set_tiles_per_block(int n);
+/*
+ * Pointwise (KS == 1, stride 1) convolution Cin -> Cout <= 160 as a pixel x channel GEMM on the fp32 MFMA: the 192 -> Kp layer that
+ * ends every probability classifier (reference prob_clf.py:71-74).  `packed_w` must come from l3c_conv_pw_pack_weights
+ * (l3c_conv_pw_packed_words(Cout, Cin) floats).  Cin % 64 == 0; bias only (epilogue == 0); input / weights 16-byte aligned and
+ * input channel stride / offset multiples of 4.  Differs from l3c_conv_mfma by the order of the Cin-term sums only.
+ */
+int64_t l3c_conv_pw_packed_words(int Cout, int Cin);
+int l3c_conv_pw_pack_weights(const float *w_oi, int Cout, int Cin, float *packed, l3c_stream_t stream);
+int l3c_conv_pw(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 /* Same contract on plain VALU FMAs with unpacked OIHW weights (packed_w = w_oihw): a device-side cross-check. */
 int l3c_conv_direct(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 

@@ -82,6 +82,9 @@ PROTOTYPES = {
     'l3c_conv_wino_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_wino': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_wino_set_tiles_per_block': (c_int, [c_int]),
+    'l3c_conv_pw_packed_words': (c_i64, [c_int, c_int]),
+    'l3c_conv_pw_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    'l3c_conv_pw': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_direct': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'l3c_to_q_quantize': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),

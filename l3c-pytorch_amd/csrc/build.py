@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_wino.hip']
+SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_wino.hip', 'conv_pw.hip']
 HEADERS = ['ac_core.h', 'l3c_common.h', os.path.join('..', '..', 'include', 'l3c_hip.h')]
 LIB = os.path.join(HERE, 'libl3c_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']

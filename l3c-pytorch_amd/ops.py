@@ -11,6 +11,9 @@ from ._lib import ConvDesc, call, ptr, stream
 _CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU cross-check kernel (debugging)
 # 3x3 / stride 1 layers (dilation 1, 2, 4) run as Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) unless L3C_CONV_WINO=0
 _CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
+# 1x1 layers with Cin % 64 == 0 and Cout <= 160 (the 192 -> Kp classifier output) run on the pointwise kernel (csrc/conv_pw.hip)
+# unless L3C_CONV_PW=0
+_CONV_PW = os.environ.get('L3C_CONV_PW', '1') != '0'
 
 # Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
 # appends (kernel key, algorithmic FLOPs, algorithmic HBM bytes, start event, end event), the events being recorded on the launch
@@ -42,6 +45,12 @@ class PackedConv(object):
             self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())
 
+        self.packed_pw = None
+        if _CONV_PW and self.KS == 1 and stride == 1 and self.Cin % 64 == 0 and self.Cout <= 160:
+            n = _lib.load().l3c_conv_pw_packed_words(self.Cout, self.Cin)
+            self.packed_pw = torch.empty(n, dtype=torch.float32, device='cuda')
+            call('l3c_conv_pw_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_pw), stream())
+
     def out_hw(self, H, W):
         pad = self.KS // 2 if self.dilation == 1 else self.dilation
         ext = (self.KS - 1) * self.dilation + 1
@@ -58,9 +67,10 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
                else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
     impl = impl or _CONV_IMPL
     wino = impl == 'mfma' and layer.packed_wino is not None and (layer.Cout % 16 == 0 or not pixel_shuffle)
+    pw = impl == 'mfma' and layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None)
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
-    d.packed_w = ptr(layer.packed_wino if wino else layer.packed if impl == 'mfma' else layer.weight)
+    d.packed_w = ptr(layer.packed_wino if wino else layer.packed_pw if pw else layer.packed if impl == 'mfma' else layer.weight)
     d.bias = ptr(layer.bias)
     d.residual = ptr(residual, torch.float32) if residual is not None else None
     d.res_cstride = residual.shape[-1] if residual is not None else 0
@@ -73,7 +83,7 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     if PROFILE is not None and impl == 'mfma':
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call('l3c_conv_wino' if wino else 'l3c_conv_mfma', d, stream())
+        call('l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma', d, stream())
         e1.record()
         key = ('conv_wino_kernel' if wino else 'conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
                'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
@@ -83,7 +93,7 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         nbytes = 4.0 * B * (H * W * layer.Cin + Ho * Wo * layer.Cout * (2 if residual is not None else 1))   # in + out (+ residual), once
         PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1))
         return out
-    call('l3c_conv_wino' if wino else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
+    call('l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
     return out
 
 

@@ -283,3 +283,36 @@ def test_winograd_at_the_headline_layer_sizes(wino_tpb, dil, Cout, B, H, W, shuf
     else:
         win = win[:, :, hs:, ws:]
     assert win.shape == ref.shape and (win.double() - ref).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize('Cin,Cout,B,H,W', [(192, 120, 1, 11, 33), (192, 150, 2, 5, 70), (64, 64, 1, 16, 8), (192, 120, 2, 128, 192),
+                                            (192, 150, 1, 1, 1), (192, 160, 1, 7, 37), (192, 33, 1, 9, 15), (192, 128, 3, 64, 96)])
+def test_pointwise_conv_vs_torch_and_implicit_gemm(Cin, Cout, B, H, W):
+    """csrc/conv_pw.hip (1x1 as a pixel x channel GEMM; tiles of 128 pixels, several tiles per block, ragged last tile, output
+    channels that do not fill the last 32-group, 4- and 5-wavefront blocks) against F.conv2d on the CPU and against the
+    implicit-GEMM 1x1 kernel: 3e-5 for unit-scale data (192-term sums in different orders); writes exactly its own channels of
+    a wider output; deterministic and batch invariant."""
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(Cout * 7 + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double())
+    layer = ops.PackedConv(w, b)
+    assert layer.packed_pw is not None
+    xd = _nhwc(x).cuda()
+    out = torch.full((B, H, W, Cout + 8), float('nan'), device='cuda')
+    ops.conv(xd, layer, out=out, out_coff=4)                                   # dispatches to l3c_conv_pw
+    got = out[..., 4:4 + Cout].cpu().permute(0, 3, 1, 2)
+    assert (got.double() - ref).abs().max().item() < 3e-5
+    assert bool(torch.isnan(out[..., :4]).all()) and bool(torch.isnan(out[..., 4 + Cout:]).all())
+    pw, layer.packed_pw = layer.packed_pw, None
+    if Cin % 16 == 0:
+        gemm = ops.conv(xd, layer).cpu().permute(0, 3, 1, 2)
+        assert (got - gemm).abs().max().item() < 3e-5
+    layer.packed_pw = pw
+    again = ops.conv(xd, layer).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(again, got)
+    if B > 1:
+        single = ops.conv(xd[1:2].contiguous(), layer).cpu().permute(0, 3, 1, 2)
+        assert torch.equal(single, got[1:2])
