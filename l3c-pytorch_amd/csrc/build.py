@@ -60,6 +60,9 @@ if __name__ == '__main__':
         kw.update(extra=['-DL3C_WINO_TIMELINE'], lib=os.path.join(HERE, 'libl3c_hip_timeline.so'), objdir='_obj_timeline')
     if '--dev-probes' in sys.argv:       # development: l3c_conv_mfma honours the probe bits of `epilogue` (tools/conv_probe.py)
         kw.update(extra=['-DL3C_DEV_PROBES'], lib=os.path.join(HERE, 'libl3c_hip_devprobes.so'), objdir='_obj_devprobes')
+    if '--variant' in sys.argv:          # development: any -D flag as an A/B variant, e.g. --variant L3C_HEAD_FILL_ROWS
+        n = sys.argv[sys.argv.index('--variant') + 1]
+        kw.update(extra=['-D' + n], lib=os.path.join(HERE, 'libl3c_hip_{}.so'.format(n.lower())), objdir='_obj_' + n.lower())
     if '--wino-probe' in sys.argv:       # development: timing probes of conv_wino_kernel with parts of it removed (wrong results)
         n = sys.argv[sys.argv.index('--wino-probe') + 1]
         kw.update(extra=['-DL3C_WINO_PROBE=' + n], lib=os.path.join(HERE, 'libl3c_hip_probe{}.so'.format(n)), objdir='_obj_probe' + n)
