@@ -76,7 +76,7 @@ constexpr int WT_H = 4, WT_W = 32;               // output tile of a block: 2 x 
 constexpr int WP_H = WT_H + 2, WP_W = WT_W + 2;  // input patch
 constexpr int N_TILES = (WT_H / 2) * (WT_W / 2);
 constexpr int WCK = 8;                           // input channels per chunk
-constexpr int WINO_TPB_MAX = 3;                  // tiles a block walks (24, 12, 6, 3 tiles per row at the L3C resolutions)
+constexpr int WINO_TPB_MAX = 6;                  // tiles a block walks (24, 12, 6, 3 tiles per row at the L3C resolutions); 3 -> 6: +1.5 %
 constexpr int PSR = 12;                          // LDS stride of a raw patch pixel (floats)
 constexpr int PSV = 8;                           // LDS stride of a transformed tile (floats), its two 4-float groups swizzled
 constexpr int RAW_FLOATS = WP_H * WP_W * PSR;
