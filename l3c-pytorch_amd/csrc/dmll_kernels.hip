@@ -63,8 +63,21 @@ __device__ __forceinline__ MixComponent mix_component(Get get, const MixStats &s
     return m;
 }
 
+// sigmoid_f with its two saturated ends taken EXACTLY, without the expf and the division -- same bits as sigmoid_f:
+//   a >= 16.7:  expf(-a) <= 5.6e-8 < 2^-24, so 1.0f + expf(-a) rounds to 1.0f and the quotient is 1.0f;
+//   a <= -89:   expf(-a) overflows to +inf (e^89 > FLT_MAX), 1.0f + inf = inf, 1.0f / inf = 0.0f.
+// (Between -89 and -16.7 the value is tiny but not zero and has to be computed.)  A CDF row evaluates every mixture component
+// at all Lp targets; a component only has unsaturated terms within (-89 .. 16.7) sigma of its mean -- for the entries above
+// that band, usually most of the row, the ~25 instructions of expf + division are skipped (a divergent branch: a wavefront
+// takes the long path only if one of its lanes needs it).
+__device__ __forceinline__ float sigmoid_sat(float a) {
+    if (a >= 16.7f) return 1.0f;
+    if (a <= -89.0f) return 0.0f;
+    return 1.0f / (1.0f + expf(-a));
+}
+
 __device__ __forceinline__ float cdf_term(float pi, float mu, float inv_sigma, float target) {
-    return pi * sigmoid_f((target - mu) * inv_sigma);
+    return pi * sigmoid_sat((target - mu) * inv_sigma);
 }
 
 __device__ __forceinline__ uint32_t cdf_quantise(float cdf, float scale, int l) {

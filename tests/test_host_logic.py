@@ -194,3 +194,19 @@ def test_tester_image_prefetch_keeps_order(tmp_path):
     assert [i for i, _, _ in got] == list(range(11)) and [p for _, p, _ in got] == ps
     for i, _, img in got:
         assert tuple(img.shape) == (3, 5 + i, 7) and int(img.max()) == i
+
+
+def test_saturated_sigmoid_shortcuts_are_exact_in_fp32():
+    """csrc/dmll_kernels.hip sigmoid_sat: the two shortcuts must reproduce 1.0f / (1.0f + expf(-a)) bit for bit, with margin for an
+    expf that is off by a few ulp (checked here with numpy's fp32 arithmetic; the GPU side is pinned by the table fixtures)."""
+    import numpy as np
+    hi = np.linspace(16.7, 120.0, 200001, dtype=np.float32)
+    e = np.exp(-hi.astype(np.float64)).astype(np.float32)
+    for scale in (np.float32(1.0), np.float32(1.0 + 8e-7), np.float32(1.0 - 8e-7)):        # expf wrong by ~7 ulp either way
+        assert np.all(np.float32(1.0) / (np.float32(1.0) + e * scale) == np.float32(1.0))
+    assert np.float32(np.exp(np.float64(-16.7))) < np.float32(2.0 ** -24)
+    with np.errstate(over='ignore'):
+        lo = np.linspace(-200.0, -89.0, 100001, dtype=np.float32)
+        e = np.exp(-lo)                                   # fp32 overflow -> inf
+        assert np.all(np.isinf(e)) and np.all(np.float32(1.0) / (np.float32(1.0) + e) == 0.0)
+    assert np.exp(np.float64(89.0)) > float(np.finfo(np.float32).max) * 1.3                       # e^89 overflows fp32 with margin
