@@ -67,6 +67,8 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
                else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
     impl = impl or _CONV_IMPL
     wino = impl == 'mfma' and layer.packed_wino is not None and (layer.Cout % 16 == 0 or not pixel_shuffle)
+    if wino and H * W * cstride * 4 >= 0x7ffffff0 and layer.packed is not None:
+        wino = False     # the Winograd kernel addresses one input image with 32-bit offsets; beyond 2 GB the implicit GEMM (64-bit) takes over
     pw = impl == 'mfma' and layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None)
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
