@@ -14,7 +14,7 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int RH_TH = 8, RH_TW = 32;
+constexpr int RH_TH = 8, RH_TW = 32, RH_NT = 4;   // tile of the 3x3 head; tiles a block walks down its column
 
 __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__ img, const float *__restrict__ w1,
                                                        const float *__restrict__ b1, const float *__restrict__ w2,
@@ -27,60 +27,66 @@ __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__
     constexpr int IH = RH_TH + 2, IW = RH_TW + 2;
     const int tid = threadIdx.x;
     const int b = blockIdx.z;
-    const int oy0 = blockIdx.y * RH_TH, ox0 = blockIdx.x * RH_TW;
+    const int ox0 = blockIdx.x * RH_TW;
     for (int i = tid; i < 27 * Cf; i += 256) {
         const int co = i % Cf, r = i / Cf;               // r = (ky*3+kx)*3 + ci
         const int ci = r % 3, tap = r / 3;
         s_w[i] = w3[((size_t)co * 3 + ci) * 9 + tap];
-    }
-    const size_t plane = (size_t)H * W;
-    const float *im = img + (size_t)b * 3 * plane;
-    for (int i = tid; i < IH * IW; i += 256) {
-        const int r = i / IW, c = i % IW;
-        const int y = oy0 + r - 1, x = ox0 + c - 1;
-        float z[3] = {0.f, 0.f, 0.f};
-        if (y >= 0 && y < H && x >= 0 && x < W) {
-            float v[3], u[3];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[k] = im[k * plane + (size_t)y * W + x];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) u[o] = ((v[0] * w1[o * 3 + 0] + v[1] * w1[o * 3 + 1]) + v[2] * w1[o * 3 + 2]) + b1[o];
-#pragma unroll
-            for (int o = 0; o < 3; ++o) z[o] = ((u[0] * w2[o * 3 + 0] + u[1] * w2[o * 3 + 1]) + u[2] * w2[o * 3 + 2]) + b2[o];
-            if (shifted_out && r >= 1 && r <= RH_TH && c >= 1 && c <= RH_TW) {
-#pragma unroll
-                for (int o = 0; o < 3; ++o) shifted_out[((size_t)b * 3 + o) * plane + (size_t)y * W + x] = z[o];
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 3; ++o) s_in[(o * IH + r) * IW + c] = z[o];
     }
     __syncthreads();
     const int quads = Cf / 4;                            // 16 lanes per pixel when Cf == 64
     const int q = tid % quads;
     const int pix_per_pass = 256 / quads;
     // A thread keeps its four output channels for every pixel it visits: their 27 weight quads live in registers (read from
-    // LDS per pixel they were 4/5 of the kernel's LDS traffic, and the kernel was LDS-bound: 6.0 -> [measured below] ms for a
-    // batch of 128 768x512 images against 2.6 ms of HBM time for the 12.9 GB it writes).  Same products, same order.
+    // LDS per pixel they were 4/5 of the kernel's LDS traffic), and a block walks RH_NT tiles down its column so that the
+    // weight gather and the register fill are paid once per RH_NT * 256 pixels.  Same products, same order.
     f32x4 wreg[27];
 #pragma unroll
     for (int t = 0; t < 27; ++t) wreg[t] = *reinterpret_cast<const f32x4 *>(&s_w[t * Cf + q * 4]);
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(&b3[q * 4]);
-    for (int pp = tid / quads; pp < RH_TH * RH_TW; pp += pix_per_pass) {
-        const int r = pp / RH_TW, c = pp % RH_TW;
-        const int y = oy0 + r, x = ox0 + c;
-        if (y >= H || x >= W) continue;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const size_t plane = (size_t)H * W;
+    const float *im = img + (size_t)b * 3 * plane;
+    for (int nt = 0; nt < RH_NT; ++nt) {
+        const int oy0 = (blockIdx.y * RH_NT + nt) * RH_TH;
+        if (oy0 >= H) break;
+        if (nt) __syncthreads();                         // the previous tile's s_in is no longer read
+        for (int i = tid; i < IH * IW; i += 256) {
+            const int r = i / IW, c = i % IW;
+            const int y = oy0 + r - 1, x = ox0 + c - 1;
+            float z[3] = {0.f, 0.f, 0.f};
+            if (y >= 0 && y < H && x >= 0 && x < W) {
+                float v[3], u[3];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
+                for (int k = 0; k < 3; ++k) v[k] = im[k * plane + (size_t)y * W + x];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
+                for (int o = 0; o < 3; ++o) u[o] = ((v[0] * w1[o * 3 + 0] + v[1] * w1[o * 3 + 1]) + v[2] * w1[o * 3 + 2]) + b1[o];
 #pragma unroll
-                for (int ci = 0; ci < 3; ++ci) {
-                    const float v = s_in[(ci * IH + r + ky) * IW + c + kx];
-                    acc = acc + v * wreg[(ky * 3 + kx) * 3 + ci];
+                for (int o = 0; o < 3; ++o) z[o] = ((u[0] * w2[o * 3 + 0] + u[1] * w2[o * 3 + 1]) + u[2] * w2[o * 3 + 2]) + b2[o];
+                if (shifted_out && r >= 1 && r <= RH_TH && c >= 1 && c <= RH_TW) {
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) shifted_out[((size_t)b * 3 + o) * plane + (size_t)y * W + x] = z[o];
                 }
-        *reinterpret_cast<f32x4 *>(&out[(((size_t)b * H + y) * W + x) * Cf + q * 4]) = acc + bias;
+            }
+#pragma unroll
+            for (int o = 0; o < 3; ++o) s_in[(o * IH + r) * IW + c] = z[o];
+        }
+        __syncthreads();
+        for (int pp = tid / quads; pp < RH_TH * RH_TW; pp += pix_per_pass) {
+            const int r = pp / RH_TW, c = pp % RH_TW;
+            const int y = oy0 + r, x = ox0 + c;
+            if (y >= H || x >= W) continue;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int ci = 0; ci < 3; ++ci) {
+                        const float v = s_in[(ci * IH + r + ky) * IW + c + kx];
+                        acc = acc + v * wreg[(ky * 3 + kx) * 3 + ci];
+                    }
+            *reinterpret_cast<f32x4 *>(&out[(((size_t)b * H + y) * W + x) * Cf + q * 4]) = acc + bias;
+        }
     }
 }
 
@@ -248,7 +254,7 @@ int l3c_rgb_head(const float *img, const float *w1, const float *b1, const float
     L3C_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, "bad shape");
     L3C_REQUIRE(Cf % 4 == 0 && Cf >= 4 && Cf <= 256 && 256 % (Cf / 4) == 0, "Cf must be 4 * a divisor of 256");
     const size_t lds = (size_t)(27 * Cf + 3 * (RH_TH + 2) * (RH_TW + 2)) * sizeof(float);
-    const dim3 grid((unsigned)((W + RH_TW - 1) / RH_TW), (unsigned)((H + RH_TH - 1) / RH_TH), (unsigned)B);
+    const dim3 grid((unsigned)((W + RH_TW - 1) / RH_TW), (unsigned)((H + RH_TH * RH_NT - 1) / (RH_TH * RH_NT)), (unsigned)B);
     hipLaunchKernelGGL(rgb_head_kernel, grid, dim3(256), lds, l3c::as_stream(stream), img, w1, b1, w2, b2, w3, b3, H, W,
                        Cf, out, shifted_out);
     return l3c::check_launch("rgb_head_kernel");
