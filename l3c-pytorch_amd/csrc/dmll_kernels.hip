@@ -45,12 +45,24 @@ struct MixComponent {
 };
 
 // x0, x1: actual values of the previously coded channels (RGB scale only, c > 0).
+// e_k = expf(logit_k - max): the softmax numerator.  Callers that have just computed it for the denominator pass it in (the
+// same operation on the same operands: the same bits) instead of paying a second expf.
+template <class Get>
+__device__ __forceinline__ MixComponent mix_component_e(Get get, const MixStats &st, float e_k, int C, int K, int rgb, int c, int k,
+                                                        float x0, float x1);
+
 template <class Get>
 __device__ __forceinline__ MixComponent mix_component(Get get, const MixStats &st, int C, int K, int rgb, int c, int k,
                                                       float x0, float x1) {
+    return mix_component_e(get, st, expf(get(c * K + k) - st.max_logit), C, K, rgb, c, k, x0, x1);
+}
+
+template <class Get>
+__device__ __forceinline__ MixComponent mix_component_e(Get get, const MixStats &st, float e_k, int C, int K, int rgb, int c, int k,
+                                                        float x0, float x1) {
     const int CK = C * K;
     MixComponent m;
-    m.pi = expf(get(c * K + k) - st.max_logit) / st.denom;
+    m.pi = e_k / st.denom;
     m.mu = get(CK + c * K + k);
     m.log_sigma = fmaxf(get(2 * CK + c * K + k), kLogScalesMin);
     if (rgb && c == 1) {
@@ -273,10 +285,22 @@ __global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__re
             }
             const float t_lo = targets[x];
             const float t_hi = targets[x + 1];
-            const MixStats st = mix_stats(get, C, K, c);
+            // softmax statistics with the numerators kept (mix_stats' two loops, same operations in the same order)
+            MixStats st;
+            st.max_logit = get(c * K);
+            for (int k = 1; k < K; ++k) st.max_logit = fmaxf(st.max_logit, get(c * K + k));
+            float e[kMaxK];
+            st.denom = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                e[k] = k < K ? expf(get(c * K + k) - st.max_logit) : 0.0f;
+                if (k < K) st.denom = st.denom + e[k];
+            }
             float acc_lo = 0.0f, acc_hi = 0.0f;
-            for (int k = 0; k < K; ++k) {
-                const MixComponent m = mix_component(get, st, C, K, rgb, c, k, x0, x1);
+#pragma unroll
+            for (int k = 0; k < kMaxK; ++k) {
+                if (k >= K) break;
+                const MixComponent m = mix_component_e(get, st, e[k], C, K, rgb, c, k, x0, x1);
                 const float inv = expf(-m.log_sigma);
                 acc_lo = acc_lo + cdf_term(m.pi, m.mu, inv, t_lo);
                 acc_hi = acc_hi + cdf_term(m.pi, m.mu, inv, t_hi);
@@ -460,6 +484,7 @@ int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *t
                               int K, int rgb, int Lp, uint32_t *intervals, l3c_stream_t stream) {
     L3C_REQUIRE(P && sym && targets && intervals, "null pointer");
     L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && K > 0, "bad shape");
+    L3C_REQUIRE(K <= kMaxK, "K out of range");
     L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
     L3C_REQUIRE(Lp >= 2 && Lp <= 65536, "Lp out of range");
     const int Kp = (rgb ? 4 : 3) * C * K;
