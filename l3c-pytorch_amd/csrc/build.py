@@ -14,6 +14,9 @@ SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip',
 HEADERS = ['ac_core.h', 'l3c_common.h', os.path.join('..', '..', 'include', 'l3c_hip.h')]
 LIB = os.path.join(HERE, 'libl3c_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
+# per-source flags.  The MFMA kernels: no SLP vectorisation -- hipcc otherwise packs adjacent scalar fp32 adds of the input
+# transform into v_pk_add_f32 / v_pk_fma_f32, which beside MFMAs cost more issue time than the plain instructions they replace.
+SOURCE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_pw.hip': ['-fno-slp-vectorize']}
 
 
 def _stale(target, deps):
@@ -36,7 +39,7 @@ def build(force=False, verbose=False, extra=(), lib=LIB, objdir='_obj'):
         o = os.path.join(HERE, objdir, src.replace('.hip', '.o'))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + list(extra) + os.environ.get('HIPCC_EXTRA', '').split() + ['-c', s, '-o', o]
+            cmd = [hipcc] + FLAGS + SOURCE_FLAGS.get(src, []) + list(extra) + os.environ.get('HIPCC_EXTRA', '').split() + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -60,9 +63,10 @@ if __name__ == '__main__':
         kw.update(extra=['-DL3C_WINO_TIMELINE'], lib=os.path.join(HERE, 'libl3c_hip_timeline.so'), objdir='_obj_timeline')
     if '--dev-probes' in sys.argv:       # development: l3c_conv_mfma honours the probe bits of `epilogue` (tools/conv_probe.py)
         kw.update(extra=['-DL3C_DEV_PROBES'], lib=os.path.join(HERE, 'libl3c_hip_devprobes.so'), objdir='_obj_devprobes')
-    if '--variant' in sys.argv:          # development: any -D flag as an A/B variant, e.g. --variant L3C_HEAD_FILL_ROWS
+    if '--variant' in sys.argv:          # development: an A/B build with extra compiler flags: --variant NAME "-DX -fno-slp-vectorize"
         n = sys.argv[sys.argv.index('--variant') + 1]
-        kw.update(extra=['-D' + n], lib=os.path.join(HERE, 'libl3c_hip_{}.so'.format(n.lower())), objdir='_obj_' + n.lower())
+        flags = sys.argv[sys.argv.index('--variant') + 2].split()
+        kw.update(extra=flags, lib=os.path.join(HERE, 'libl3c_hip_{}.so'.format(n)), objdir='_obj_l3c_' + n)
     if '--wino-probe' in sys.argv:       # development: timing probes of conv_wino_kernel with parts of it removed (wrong results)
         n = sys.argv[sys.argv.index('--wino-probe') + 1]
         kw.update(extra=['-DL3C_WINO_PROBE=' + n], lib=os.path.join(HERE, 'libl3c_hip_probe{}.so'.format(n)), objdir='_obj_probe' + n)

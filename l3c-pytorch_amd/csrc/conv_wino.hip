@@ -111,6 +111,14 @@ __device__ __forceinline__ int xcd_remap_w(int bid, int total) {
 #define L3C_WINO_STAMP(i)
 #endif
 
+// a - b as ONE plain v_sub_f32 (the optimiser folds extract / subtract / insert on the two halves of a float2 back into a packed
+// v_pk_add_f32 whatever the source says; an asm statement it cannot)
+__device__ __forceinline__ float sub_scalar(float a, float b) {
+    float r;
+    asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // RELU / RES / SHUFFLE: the epilogue variant, compile-time (no per-element selects).
 //
 // A block walks n_t <= p.tpb horizontally adjacent tiles (same image, sub-grid, tile row and output-channel chunk, hence the
@@ -232,17 +240,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
     const int t_dst = (t_ty * 16 + t_tx) * PSV + (((t_cq >> 1) ^ (t_tx >> 3)) * 4) + (t_cq & 1) * 2 + (2 * t_h * 4) * N_TILES * PSV;
     f32x2 d[3][4], e[2][4];
     auto transform_load = [&](int par, int i) {   // i = 0, 1, 2: x, y, z
-        int row_off = t_row[i] * WP_W * PSR;
-        asm volatile("" : "+s"(row_off));   // added per use: three precomputed per-lane addresses would cost two more registers
-        const float *src = raw_buf(par) + t_src + row_off;
+        const float *src = raw_buf(par) + t_src + t_row[i] * WP_W * PSR;   // (three per-lane addresses, hoisted out of the loop)
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[i][j] = *reinterpret_cast<const f32x2 *>(src + j * PSR);
     };
     auto transform_rows = [&](int k) {   // e[k] = row 2 t_h + k of B^T d
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (k == 0) {
-                e[0][j] = d[0][j] - d[2][j];
+            if (k == 0) {   // (component-wise on purpose, and the file is built with -fno-slp-vectorize: packed fp32 VALU beside MFMAs
+                            // costs more issue time than two plain ones -- MI355X_MICROARCH.md, "price of one filler")
+                e[0][j][0] = sub_scalar(d[0][j][0], d[2][j][0]);
+                e[0][j][1] = sub_scalar(d[0][j][1], d[2][j][1]);
             } else {   // s = +-1: the product is exact
                 e[1][j][0] = __builtin_fmaf(t_s, d[1][j][0], d[2][j][0]);
                 e[1][j][1] = __builtin_fmaf(t_s, d[1][j][1], d[2][j][1]);
@@ -250,11 +258,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
         }
     };
     auto transform_cols = [&](int k) {   // e[k] <- e[k] B
-        const f32x2 c0 = e[k][0] - e[k][2], c1 = e[k][1] + e[k][2], c2 = e[k][2] - e[k][1], c3 = e[k][1] - e[k][3];
-        e[k][0] = c0;
-        e[k][1] = c1;
-        e[k][2] = c2;
-        e[k][3] = c3;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float c0 = e[k][0][h] - e[k][2][h], c1 = e[k][1][h] + e[k][2][h], c2 = e[k][2][h] - e[k][1][h], c3 = e[k][1][h] - e[k][3][h];
+            e[k][0][h] = c0;
+            e[k][1][h] = c1;
+            e[k][2][h] = c2;
+            e[k][3][h] = c3;
+        }
     };
     auto transform_write = [&](float *Vdst, int k) {   // finished row 2 t_h + k -> positions 4 (2 t_h + k) .. + 3
         float *dst = Vdst + t_dst + (k * 4) * N_TILES * PSV;
@@ -371,6 +382,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             L3C_WINO_MFMA(q + 1, 0, A1, B1)
             if (pp < 3) a1[nb] = *reinterpret_cast<const f32x4 *>(a_cur + a_pos(q + 3));
             L3C_WINO_MFMA(q, 1, A0, B0)
+            if (pp == 3) pf_advance();       // the prefetch pointer moves on (into the next tile: new column offsets); in a gap of its
+                                             // own: its (rarely taken) branch ends a basic block, and work placed behind it bunches up there
             if (pp == 0 && !(L3C_WINO_PROBE & 2)) store_pieces(par, stage_regs[par]);   // patch g + 2 -> raw[g & 1] (its previous patch was transformed during g - 1)
             if (pp == 1 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 1);
             if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_cols(0);
@@ -385,7 +398,6 @@ __global__ __launch_bounds__(256, 2) void conv_wino_kernel(const WinoParams p) {
             L3C_WINO_MFMA(q + 1, 2, A1, B1)
             if (pp == 0) fetch_patch_piece(par, 1);
             if (pp == 0 && !(L3C_WINO_PROBE & 4)) transform_load(par ^ 1, 2);
-            if (pp == 1) pf_advance();       // the prefetch pointer moves on (into the next tile: new column offsets)
             if (pp == 2 && !(L3C_WINO_PROBE & 4)) transform_write(v_next, 1);
             L3C_WINO_MFMA(q, 3, A0, B0)
             if constexpr (!(L3C_WINO_PROBE & 8)) fetch_b(cc_b, q);
