@@ -316,3 +316,63 @@ def test_pointwise_conv_vs_torch_and_implicit_gemm(Cin, Cout, B, H, W):
     if B > 1:
         single = ops.conv(xd[1:2].contiguous(), layer).cpu().permute(0, 3, 1, 2)
         assert torch.equal(single, got[1:2])
+
+
+def test_winograd_random_shapes_vs_implicit_gemm(wino_tpb):
+    """40 seeded random layer shapes (sizes 1..150 x 1..300, every dilation, every epilogue, random tiles-per-block setting, output
+    written into a channel slice of a wider NaN-poisoned tensor) through the Winograd kernel and the implicit-GEMM kernel: equal
+    within 3e-5, nothing written outside the slice."""
+    from l3c_pytorch_amd import ops
+    rng = np.random.RandomState(1234)
+    g = torch.Generator().manual_seed(99)
+    for case in range(40):
+        dil = int(rng.choice([1, 1, 2, 4]))
+        H, W = int(rng.randint(1, 151)), int(rng.randint(1, 301))
+        B = int(rng.randint(1, 4))
+        mode = int(rng.randint(0, 4)) if dil == 1 else int(rng.randint(0, 3))     # 0 plain, 1 relu, 2 residual, 3 pixel shuffle
+        Cout = 256 if mode == 3 else int(rng.choice([64, 64, 120, 128]))
+        Cin = int(rng.choice([64, 64, 16, 32]))
+        wino_tpb(int(rng.choice([0, 1, 2, 3, 5, 6])))
+        x = torch.randn(B, H, W, Cin, generator=g).cuda()
+        w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+        b = torch.randn(Cout, generator=g)
+        r = torch.randn(B, H, W, Cout, generator=g).cuda() if mode == 2 else None
+        layer = ops.PackedConv(w, b, dilation=dil)
+        kw = dict(relu=mode == 1, residual=r, pixel_shuffle=mode == 3)
+        co = Cout // 4 if mode == 3 else Cout
+        Ho, Wo = (2 * H, 2 * W) if mode == 3 else (H, W)
+        out = torch.full((B, Ho, Wo, co + 8), float('nan'), device='cuda')
+        ops.conv(x, layer, out=out, out_coff=4, **kw)
+        wino, layer.packed_wino = layer.packed_wino, None
+        ref = ops.conv(x, layer, **kw)
+        layer.packed_wino = wino
+        got = out[..., 4:4 + co]
+        assert not bool(torch.isnan(got).any()), (case, dil, H, W, B, mode, Cout, Cin)
+        assert (got - ref).abs().max().item() < 3e-5, (case, dil, H, W, B, mode, Cout, Cin)
+        assert bool(torch.isnan(out[..., :4]).all()) and bool(torch.isnan(out[..., 4 + co:]).all()), case
+
+
+def test_pointwise_random_shapes_vs_implicit_gemm():
+    """30 seeded random shapes of the pointwise kernel (pixel counts around the 128-pixel tile and the tiles-per-block boundaries,
+    Cout 1..160, Cin 64..256) against the implicit-GEMM 1x1 kernel: within 3e-5, nothing outside the output's channel slice."""
+    from l3c_pytorch_amd import ops
+    rng = np.random.RandomState(4321)
+    g = torch.Generator().manual_seed(7)
+    for case in range(30):
+        Cin = int(rng.choice([64, 128, 192, 192, 256]))
+        Cout = int(rng.randint(1, 161))
+        B, H, W = int(rng.randint(1, 4)), int(rng.randint(1, 70)), int(rng.randint(1, 130))
+        x = torch.randn(B, H, W, Cin, generator=g).cuda()
+        w = torch.randn(Cout, Cin, 1, 1, generator=g) / np.sqrt(Cin)
+        b = torch.randn(Cout, generator=g)
+        layer = ops.PackedConv(w, b)
+        assert layer.packed_pw is not None
+        out = torch.full((B, H, W, Cout + 5), float('nan'), device='cuda')
+        ops.conv(x, layer, out=out, out_coff=2)
+        pw, layer.packed_pw = layer.packed_pw, None
+        ref = ops.conv(x, layer)
+        layer.packed_pw = pw
+        got = out[..., 2:2 + Cout]
+        assert not bool(torch.isnan(got).any()), (case, Cin, Cout, B, H, W)
+        assert (got - ref).abs().max().item() < 3e-5, (case, Cin, Cout, B, H, W)
+        assert bool(torch.isnan(out[..., :2]).all()) and bool(torch.isnan(out[..., 2 + Cout:]).all()), case
