@@ -218,7 +218,9 @@ class Bitcoding(object):
             self.compute_stream = _lib.cu_range_stream(0, n_cu - coder_cus)
             self._coder_range = (n_cu - coder_cus, coder_cus)
 
-    N_SIDE_STREAMS = 4
+    # [measured, profiles/r02_coder_streams_small_batches.log] 8 or 12 side streams do not help with the runtime's default of four
+    # hardware queues (they alias); with GPU_MAX_HW_QUEUES=8, four streams reach 27.8 / 75.7 MPix/s at 1 / 4 images per step
+    N_SIDE_STREAMS = int(os.environ.get('L3C_CODER_STREAMS', '4'))
 
     def _side_stream(self):
         """Side stream for the range coder: its launches are a handful of long-running wavefronts (a lane per stream),
