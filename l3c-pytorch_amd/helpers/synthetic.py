@@ -9,7 +9,15 @@ build container (which makes tests/golden/*) and the GPU box regenerate bit-iden
 `levels` is written as `to_bn(arange(L))` = arange(L) * bin + x_min in fp32 -- the value the decoder reconstructs
 (quantizer.py:44-47).  A torch>=2 `linspace` differs from it by 1 ulp at 14/25 levels, which breaks the reference's own
 losslessness for fresh checkpoints; checkpoints trained with torch 1.1 carry matching levels.
+
+`make_state_dict(config_ms, seed, calibrated=True)` overlays the tensors of `calibrated/<config>_seed<k>.npz` (the last 1x1
+layer of every probability classifier and the bottleneck projections `to_q`, fitted in closed form on synthetic images by
+tests/golden/make_calibrated.py): a default-init model predicts mixtures near 0 for pixels in 0..255 and codes two of the three
+RGB streams at the 16-bit probability floor; the calibrated one is a working probability model (~6 bpsp on the bench's
+images, every bottleneck level in use, log sigma from below the clamp at -7 up to ~5.5), which is the regime a trained
+checkpoint puts the head, the tables and both coders in.
 """
+import os
 import math
 import zlib
 
@@ -30,7 +38,32 @@ def _gen(key, seed):
     return g
 
 
-def make_state_dict(config_ms, seed=0):
+CALIBRATED_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'calibrated')
+
+
+def calibrated_name(config_ms):
+    """The built-in config a calibration overlay exists for."""
+    if config_ms.rgb_bicubic_baseline:
+        return 'cr_rgb_shared' if config_ms.num_scales == 1 else None
+    return 'cr'
+
+
+def make_state_dict(config_ms, seed=0, calibrated=False):
+    sd = _default_init(config_ms, seed)
+    if calibrated:
+        name = calibrated_name(config_ms)
+        path = os.path.join(CALIBRATED_DIR, '{}_seed{}.npz'.format(name, seed))
+        if name is None or not os.path.isfile(path):
+            raise FileNotFoundError('no calibrated overlay for this config / seed: {}'.format(path))
+        with np.load(path) as z:
+            for key in z.files:
+                t = torch.from_numpy(z[key].copy())
+                assert key in sd and tuple(sd[key].shape) == tuple(t.shape), key
+                sd[key] = t
+    return sd
+
+
+def _default_init(config_ms, seed=0):
     sd = {}
     for key, shape in _schema.param_schema(config_ms).items():
         if key.endswith('levels'):

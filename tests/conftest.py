@@ -37,3 +37,24 @@ def synthetic_l3c():
     from l3c_pytorch_amd.helpers import config_parser, synthetic
     cfg = config_parser.parse_builtin('ms', 'cr')
     return cfg, synthetic.make_state_dict(cfg, 0)
+
+
+@pytest.fixture(scope='session')
+def synthetic_l3c_cal():
+    """(config_ms, state_dict) of the CALIBRATED synthetic checkpoint (tests/golden/make_calibrated.py): mixtures that cover the
+    data, every bottleneck level in use."""
+    import l3c_pytorch_amd  # noqa: F401
+    from l3c_pytorch_amd.helpers import config_parser, synthetic
+    cfg = config_parser.parse_builtin('ms', 'cr')
+    return cfg, synthetic.make_state_dict(cfg, 0, calibrated=True)
+
+
+# (fixture file, uses the calibrated checkpoint): every reference-generated L3C network fixture
+NET_FIXTURES = [('net_32.npz', False), ('net_cal_32.npz', True), ('net_cal_64x96.npz', True)]
+
+
+@pytest.fixture(scope='session')
+def l3c_checkpoint(synthetic_l3c, synthetic_l3c_cal):
+    def get(calibrated):
+        return synthetic_l3c_cal if calibrated else synthetic_l3c
+    return get

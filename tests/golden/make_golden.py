@@ -11,6 +11,7 @@ modules imported through oracle/ref_import.py) on seeded inputs that the tests c
   sample_32.npz  sampling:      MultiscaleBlueprint.sample_forward (multiscale_network.py:328-406) with the CPU generator seeded,
                                 for the sample_scales the reference's tester uses ([], [0], [0, 1]; multiscale_tester.py:443-445)
                                 and [0, 1, 2] (uniform prior on the coarsest scale)
+  net_cal_32.npz, net_cal_64x96.npz   the net_32 fixture on the calibrated checkpoint + natural-like images (round 3)
   net_32.npz     config[0]:     MultiscaleBlueprint.forward / get_loss, DiscretizedMixLogisticLoss.cdf_step_non_shared,
                                 MultiscaleNetwork.get_P, Bitcoding.encode -> file bytes, Bitcoding.decode
                                 on one 32x32 image with the synthetic checkpoint (helpers/synthetic.py, seed 0)
@@ -159,11 +160,11 @@ def make_cdf_kat(ref_torchac, ref_bitcoding, ref_coders_helpers, ref_dmll_cls):
 # network / container fixture (config[0]: one 32x32 image, CPU)
 
 
-def make_net_fixture(H=32, W=32, seed=0, img_seed=0):
+def make_net_fixture(H=32, W=32, seed=0, img_seed=0, kind='uniform', calibrated=False, fname='net_32.npz', p0_stride=1):
     cfg_mine = config_parser.parse_builtin('ms', 'cr')
-    sd = synthetic.make_state_dict(cfg_mine, seed)
-    img = synthetic.make_image(H, W, img_seed, 'uniform').unsqueeze(0).long()
-    out = {}
+    sd = synthetic.make_state_dict(cfg_mine, seed, calibrated=calibrated)
+    img = synthetic.make_image(H, W, img_seed, kind).unsqueeze(0).long()
+    out = {'p0_stride': np.array(p0_stride)}
     with ref_import.reference_modules():
         from fjcommon import config_parser as rcp, no_op
         from blueprints.multiscale_blueprint import MultiscaleBlueprint
@@ -180,7 +181,7 @@ def make_net_fixture(H=32, W=32, seed=0, img_seed=0):
             for s in range(4):
                 out['S%d' % s] = o.S[s].numpy().astype(np.int16)
             for s in range(3):
-                out['P%d' % s] = o.P[s].numpy().copy()
+                out['P%d' % s] = (o.P[s][:, :, ::p0_stride, ::p0_stride] if s == 0 else o.P[s]).numpy().copy()
                 out['bn%d' % (s + 1)] = o.bn[s + 1].numpy()
             out['bpsp'] = np.array([float(b) for b in loss.nonrecursive_bpsps], dtype=np.float64)
             # stage-wise intermediates (P2 parity ladder: feed each stage the reference's own inputs)
@@ -188,22 +189,29 @@ def make_net_fixture(H=32, W=32, seed=0, img_seed=0):
             inp = x
             for s in range(3):
                 inp = bp.net.heads[s](inp)
-                out['enc_in%d' % s] = inp.numpy().copy()
+                if p0_stride == 1:
+                    out['enc_in%d' % s] = inp.numpy().copy()
                 e = bp.net.nets[s].enc(inp)
-                out['enc_F%d' % s] = e.F.numpy().copy()
+                if p0_stride == 1 or s > 0:
+                    out['enc_F%d' % s] = e.F.numpy().copy()
                 out['enc_bn%d' % s] = e.bn.numpy().copy() if False else bp.net.nets[s].enc.to_q(e.F).numpy().copy()
                 inp = e.F
             f_prev = None
             for s in (2, 1, 0):
                 P, f_prev = bp.net.get_P(s, o.bn[s + 1], f_prev)
                 assert (P == o.P[s]).all()
-                out['dec_F%d' % s] = f_prev.numpy().copy()
+                if p0_stride == 1 or s > 0:
+                    out['dec_F%d' % s] = f_prev.numpy().copy()
             # per-channel coding parameters (logistic_mixture.py:134-141); clone P: the reference mutates it in place
             for s, dm, C, x_c in [(0, bp.losses.loss_dmol_rgb, 3, img.float()),
                                   (1, bp.losses.loss_dmol_n, 5, o.bn[1])]:
                 helper = coders_helpers.CodingCDFNonshared(o.P[s].clone(), total_C=C, dmll=dm)
                 for c in range(C):
                     cd = helper.get_next_C(x_c)
+                    if p0_stride != 1 and s == 0:
+                        if c == 2:      # the doubly lambda-coupled means only (fixture size)
+                            out['cdfout0_c2/mu'] = cd.means_c[:, :, ::p0_stride, ::p0_stride].numpy().copy()
+                        continue
                     if c == 0 or (s == 1 and c == 4):
                         out['cdfout%d_c%d/pi' % (s, c)] = cd.logit_probs_c_sm.numpy().copy()
                         out['cdfout%d_c%d/log_sigma' % (s, c)] = cd.log_scales_c.numpy().copy()
@@ -221,7 +229,7 @@ def make_net_fixture(H=32, W=32, seed=0, img_seed=0):
             out['l3c'] = np.frombuffer(data, dtype=np.uint8)
             out['l3c_bpsp'] = np.array(bpsp_file)
             print('  net: bpsp', out['bpsp'], 'file', len(data), 'bytes ->', bpsp_file)
-    np.savez_compressed(os.path.join(HERE, 'net_32.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, fname), **out)
 
 
 def make_rgb_fixtures():
@@ -278,7 +286,18 @@ def make_sample_fixture(H=32, W=32, seed=0, img_seed=3):
     np.savez_compressed(os.path.join(HERE, 'sample_32.npz'), **out)
 
 
+def make_calibrated_fixtures():
+    """The same fixture on the CALIBRATED checkpoint (helpers/synthetic.make_state_dict(calibrated=True), fitted by
+    make_calibrated.py) and natural-like images: mixtures that cover the data, every bottleneck level in use -- the regime in which
+    a P error can move a table entry and a quantiser boundary.  The real reference encodes and decodes them (asserted above)."""
+    make_net_fixture(32, 32, 0, 5, 'natural', True, 'net_cal_32.npz')
+    make_net_fixture(64, 96, 0, 6, 'natural', True, 'net_cal_64x96.npz', p0_stride=2)
+
+
 def main():
+    if '--calibrated-only' in sys.argv:
+        make_calibrated_fixtures()
+        return
     with ref_import.reference_modules():
         import torchac_backend_cpu
         from torchac import torchac as ref_torchac
@@ -294,6 +313,8 @@ def main():
     make_rgb_fixtures()
     print('sampling fixture')
     make_sample_fixture()
+    print('calibrated-checkpoint fixtures')
+    make_calibrated_fixtures()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):
             print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')

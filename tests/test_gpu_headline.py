@@ -8,8 +8,13 @@ of the bench batch):
   * coder: every stream of the image -- the three 393 216-symbol RGB streams included -- must be the C oracle's bytes for the
     table the HIP head built, and the C oracle must decode the HIP stream back (torchac.cpp:152-227, :299-381);
   * container: `.l3c` size against oracle.bitcoding.encode (bitcoding.py:50-123).
-The measured errors are written to gpurun_out/parity_768x512.json (copied to profiles/ by hand) and asserted against the
-tolerances stated in DESIGN.md section 4.
+Every test runs on BOTH synthetic checkpoints (round 3): `default` (seeded default init: mixtures near 0 for pixels in 0..255, so
+the R and G streams sit at the coder's 16-bit probability floor -- the worst case for the coder's volume, but no P error can
+move a table entry there) and `calibrated` (helpers/synthetic.make_state_dict(calibrated=True): a fitted probability model,
+~6 bpsp, all 25 bottleneck levels in use, log sigma from below the clamp to ~5.5 -- the regime a trained checkpoint puts the
+path in; asserted below).  Tolerances are RELATIVE to the largest magnitude of the tensor (or of the parameter group of P:
+logit pi / mu / log sigma / lambda): an absolute 1e-5 is below one ulp for a mean near 255.
+The measured errors are written to gpurun_out/parity_768x512_<checkpoint>.json; tools/make_evidence.sh copies them to profiles/.
 """
 import json
 import os
@@ -25,16 +30,30 @@ from oracle import ac as oracle_ac, bitcoding as obc, net as onet  # noqa: E402
 H, W = 512, 768
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 _RECORD = {}
+_CKPT = ['default']
 
 
 def _record(key, value):
-    _RECORD[key] = value
+    rec = _RECORD.setdefault(_CKPT[0], {})
+    rec[key] = value
     try:
         os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
-        with open(os.path.join(ROOT, 'gpurun_out', 'parity_768x512.json'), 'w') as f:
-            json.dump(_RECORD, f, indent=1, sort_keys=True)
+        with open(os.path.join(ROOT, 'gpurun_out', 'parity_768x512_{}.json'.format(_CKPT[0])), 'w') as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
     except OSError:
         pass
+
+
+@pytest.fixture(scope='module', params=['default', 'calibrated'])
+def synthetic_l3c(request, l3c_checkpoint):
+    """shadows conftest's fixture: every test of this module runs on both checkpoints."""
+    _CKPT[0] = request.param
+    return l3c_checkpoint(request.param == 'calibrated')
+
+
+@pytest.fixture(scope='module')
+def calibrated(synthetic_l3c):
+    return _CKPT[0] == 'calibrated'
 
 
 @pytest.fixture(scope='module')
@@ -70,15 +89,23 @@ def _err(got, ref):
     return float(d.max()), float(d.max() / ref.double().abs().max()), float(ref.abs().max())
 
 
-# tolerances: the measured errors on this image (profiles/r02_parity_768x512.json: F 2.1e-6, P 4.4e-7
-# absolute; 1.9e-6 relative to the tensor's largest magnitude) x 2.5 -- all inside north_star's 1e-5.  The two sides sum ~40
-# layers of 576-term dot products in different orders (Winograd F(2x2,3x3) on MFMA k-blocks vs the CPU's direct convolution).
+def _group_errs(P, ref, num_params):
+    """per parameter group of P (channel index = p * C * K + ...): max |diff| / max |ref| of the group."""
+    n = P.shape[1] // num_params
+    out = {}
+    for p, name in enumerate(('logit_pi', 'mu', 'log_sigma', 'lambda')[:num_params]):
+        a, r, m = _err(P[:, p * n:(p + 1) * n], ref[:, p * n:(p + 1) * n])
+        out[name] = {'max_abs': a, 'max_rel': r, 'max_value': m}
+    return out
+
+
+# tolerances (DESIGN.md section 4), RELATIVE to the largest magnitude of the tensor / parameter group: the measured errors on
+# this image (profiles/r03_parity_768x512_*.json) x ~2.5 -- all inside north_star's 1e-5.  The two sides sum ~40 layers of
+# 576-term dot products in different orders (Winograd on MFMA k-blocks vs the CPU's direct convolution).
 TOL_REL = 5e-6
-TOL_ABS_F = 5e-6
-TOL_ABS_P = 2e-6
 
 
-def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c):
+def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c, calibrated):
     """F of every encoder within tolerance; symbols equal except where the oracle's own pre-quantiser value sits within the
     F tolerance of a decision boundary (provable near-ties)."""
     _, sd = synthetic_l3c
@@ -96,10 +123,16 @@ def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c):
         worst = float(margin[bad].max()) if bad.any() else 0.0
         rec['scale%d' % s] = {'F_enc_max_abs': a, 'F_enc_max_rel': r, 'F_enc_max_value': m, 'symbol_flips': int(bad.sum()),
                               'symbols': int(bad.numel()), 'largest_margin_of_a_flip': worst}
+        rec['scale%d' % s]['levels_used'] = int(torch.unique(hip_out.S[s + 1]).numel())
         _record('encoder', rec)
-        assert a < TOL_ABS_F and r < TOL_REL, (s, a, r)
-        assert worst < 1e-4, (s, worst)                  # a flipped symbol must be a near-tie (to_q amplifies F's error ~5x)
-        assert bad.float().mean() < 1e-4, (s, int(bad.sum()))
+        assert r < TOL_REL, (s, a, r)
+        # a flipped symbol must be a near-tie of the oracle's own pre-quantiser value (to_q amplifies F's error: its rows have
+        # an L1 norm of ~5 on the default and up to ~40 on the calibrated checkpoint)
+        gain = float(sd['nets.{}.enc.to_q.0.weight'.format(s)].abs().sum(1).max())
+        assert worst < 4 * gain * TOL_REL * m + 1e-6, (s, worst, gain)
+        assert bad.float().mean() < 2e-4, (s, int(bad.sum()))
+        if calibrated:
+            assert rec['scale%d' % s]['levels_used'] >= 20, rec
 
 
 def test_decoder_side_and_P_vs_oracle_at_768x512(oracle_out, blueprint):
@@ -110,11 +143,14 @@ def test_decoder_side_and_P_vs_oracle_at_768x512(oracle_out, blueprint):
         P, f_prev = blueprint.net.get_P(s, oracle_out.bn[s + 1].cuda(), f_prev)
         fa, fr, fm = _err(f_prev.cpu(), oracle_out.F_dec[s])
         pa, pr, pm = _err(P.cpu(), oracle_out.P[s])
+        groups = _group_errs(P.cpu(), oracle_out.P[s], 4 if s == 0 else 3)
         rec['scale%d' % s] = {'F_dec_max_abs': fa, 'F_dec_max_rel': fr, 'F_dec_max_value': fm,
-                              'P_max_abs': pa, 'P_max_rel': pr, 'P_max_value': pm}
+                              'P_max_abs': pa, 'P_max_rel': pr, 'P_max_value': pm, 'P_groups': groups}
         _record('decoder', rec)
-        assert fa < TOL_ABS_F and fr < TOL_REL, (s, fa, fr)
-        assert pa < TOL_ABS_P and pr < TOL_REL, (s, pa, pr)
+        assert fr < TOL_REL, (s, fa, fr)
+        assert pr < TOL_REL, (s, pa, pr)
+        for name, g in groups.items():
+            assert g['max_abs'] < TOL_REL * max(g['max_value'], 1.0), (s, name, g)
 
 
 def test_forward_P_equals_get_P_on_own_bottlenecks_at_768x512(hip_out, blueprint):
@@ -125,7 +161,7 @@ def test_forward_P_equals_get_P_on_own_bottlenecks_at_768x512(hip_out, blueprint
         assert torch.equal(P, hip_out.P[s]), s
 
 
-def test_every_stream_is_the_oracle_coders_at_768x512(image, hip_out, blueprint):
+def test_every_stream_is_the_oracle_coders_at_768x512(image, hip_out, blueprint, calibrated):
     """For each of the 18 streams of the image: the bytes of the HIP range coder == the C oracle's bytes for the uint16 table
     the HIP head builds (P1': the fused encoder intervals are the table's entries), and the C oracle decodes them back."""
     from l3c_pytorch_amd import ops
@@ -134,7 +170,7 @@ def test_every_stream_is_the_oracle_coders_at_768x512(image, hip_out, blueprint)
     enc = bc.encode_batch(image, out=hip_out)
     payloads = enc.payloads()                                   # coarse -> fine, [scale][b][c]
     K = blueprint.net.config_ms.prob.K
-    sizes = {}
+    sizes, floor = {}, {}
     for k, (scale, dmll, uniform) in enumerate(bc.iter_scale_dmll()):
         sym = hip_out.raw.sym[scale]
         _, C, Hs, Ws = sym.shape
@@ -151,13 +187,29 @@ def test_every_stream_is_the_oracle_coders_at_768x512(image, hip_out, blueprint)
             back = oracle_ac.decode(table, got, N=Hs * Ws)
             assert np.array_equal(back, s_np), (scale, c)
             sizes['scale%d_c%d' % (scale, c)] = len(got)
+            if not uniform:   # share of symbols coded with a width-1 interval (the probability floor) and of saturated entries
+                tab = table.reshape(-1, table.shape[-1]).astype(np.int64)
+                idx = np.arange(len(s_np))
+                lo = tab[idx, s_np]
+                hi = np.where(s_np == tab.shape[1] - 2, 65536, tab[idx, np.minimum(s_np + 1, tab.shape[1] - 1)])
+                floor['scale%d_c%d' % (scale, c)] = {
+                    'width1_share': float((hi - lo == 1).mean()),
+                    'bits_per_symbol': float(len(got) * 8 / len(s_np)),
+                    'width1_table_steps_share': float((np.diff(tab[:, :-1], axis=1) == 1).mean())}
     _record('stream_bytes', sizes)
-    assert max(sizes.values()) > 300000                        # the RGB streams really are the long ones
+    _record('probability_floor', floor)
+    assert max(sizes.values()) > 100000                        # the RGB streams really are the long ones
+    if calibrated:      # the workload is non-degenerate: the probability model is live on every stream
+        for k, v in floor.items():
+            assert v['width1_share'] < 0.05, (k, v)
+        assert sum(sizes.values()) * 8 / (3 * H * W) < 8.0
 
 
 def test_file_size_vs_oracle_and_round_trip_at_768x512(image, hip_out, blueprint, synthetic_l3c):
-    """`.l3c` of the image: size within 64 bytes of oracle.bitcoding.encode (2.38 MB; the two sides' P differ in the last bits,
-    which moves a table entry by 1 here and there -- SURVEY.md section 8c), per-scale framing identical, decode lossless."""
+    """`.l3c` of the image: size within 64 bytes + 1e-4 of oracle.bitcoding.encode's (2.38 MB on the default, ~0.9 MB on the
+    calibrated checkpoint; the two sides' P differ in the last bits, which moves a table entry by 1 here and there -- SURVEY.md
+    section 8c -- and on the calibrated checkpoint may flip a near-tie bottleneck symbol), per-scale framing identical, decode
+    lossless."""
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
     _, sd = synthetic_l3c
     bc = Bitcoding(blueprint)
@@ -166,7 +218,7 @@ def test_file_size_vs_oracle_and_round_trip_at_768x512(image, hip_out, blueprint
         ref = obc.encode(image.long(), sd)
     _record('file', {'hip_bytes': len(data), 'oracle_bytes': len(ref), 'delta': len(data) - len(ref)})
     assert data[:13] == ref[:13]                                # padding tuple + the coarsest scale's header
-    assert abs(len(data) - len(ref)) <= 64, (len(data), len(ref))
+    assert abs(len(data) - len(ref)) <= 64 + 1e-4 * len(ref), (len(data), len(ref))
     dec, _ = bc.decode_batch([data])
     assert torch.equal(dec.cpu(), image.long())
 

@@ -9,16 +9,31 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import bitcoding as obc, net as onet  # noqa: E402
+from tests.conftest import NET_FIXTURES  # noqa: E402
 
 
-@pytest.fixture(scope='module')
-def blueprint(synthetic_l3c):
+def _make_blueprint(cfg, sd):
     from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
-    cfg, sd = synthetic_l3c
     bp = MultiscaleBlueprint(cfg)
     bp.net.load_state_dict(sd, strict=True)
     bp.set_eval()
     return bp
+
+
+@pytest.fixture(scope='module')
+def blueprint(synthetic_l3c):
+    return _make_blueprint(*synthetic_l3c)
+
+
+@pytest.fixture(scope='module')
+def blueprint_cal(synthetic_l3c_cal):
+    """the same network with the CALIBRATED checkpoint (live probability model; tests/golden/make_calibrated.py)."""
+    return _make_blueprint(*synthetic_l3c_cal)
+
+
+@pytest.fixture(scope='module')
+def blueprints(blueprint, blueprint_cal):
+    return lambda calibrated: blueprint_cal if calibrated else blueprint
 
 
 def _near_tie(x_prequant, levels, tol=5e-5):
@@ -26,71 +41,93 @@ def _near_tie(x_prequant, levels, tol=5e-5):
     return (d[..., 1] - d[..., 0]) < tol
 
 
-# Tolerances of the network parity tests (measured on the MI355X: F within 2.1e-6, P within 4.4e-7 at
-# 768x512 -- tests/test_gpu_headline.py records them -- and no larger on the small images here): north_star's 1e-5, absolute.
+# Tolerances of the network parity tests (measured on the MI355X at 768x512 -- tests/test_gpu_headline.py
+# records them -- and no larger on the small images here): north_star's 1e-5, RELATIVE to the tensor's largest magnitude (floored
+# at 1: the default-init checkpoint's tensors stay below 1.2, the calibrated one's means reach 280, where 1 ulp is 3e-5).
 TOL_F = 1e-5
 TOL_P = 1e-5
 
 
-def _symbols_equal_up_to_near_ties(S, S_ref, bn_ref, levels):
+def _tol(ref, tol):
+    return tol * max(float(np.abs(np.asarray(ref)).max()), 1.0)
+
+
+def _symbols_equal_up_to_near_ties(S, S_ref, bn_ref, levels, tol=5e-5):
     """-> number of flipped symbols; every flip must sit where the REFERENCE's own pre-quantiser value is within 5e-5 of a
-    decision boundary (to_q sums 64 features: a 1e-5 difference in F moves it by a few 1e-5)."""
+    decision boundary (to_q sums 64 features: a 1e-5 difference in F moves it by a few 1e-5; the calibrated checkpoint's to_q
+    rows are ~10x larger -- they spread the bottleneck over all 25 levels -- hence 5e-4 there)."""
     bad = S != S_ref
-    assert bad.sum() == 0 or _near_tie(bn_ref, levels)[bad].all()
+    assert bad.sum() == 0 or _near_tie(bn_ref, levels, tol)[bad].all()
     return int(bad.sum())
 
 
-def test_forward_matches_reference_fixture(golden, blueprint, synthetic_l3c):
-    """config[0] (32x32) against the reference's own CPU forward (tests/golden/net_32.npz): encoder features within 1e-5,
-    symbols identical except provable quantiser near-ties, P within 1e-5 -- through get_P on the reference's bottlenecks, so
-    that a flipped symbol cannot void the comparison -- and per-scale bpsp within 1e-4 relative (+ 16 bits per flipped symbol)."""
-    cfg, sd = synthetic_l3c
-    g = golden('net_32.npz')
+@pytest.mark.parametrize('fixture,calibrated', NET_FIXTURES)
+def test_forward_matches_reference_fixture(golden, blueprints, l3c_checkpoint, fixture, calibrated):
+    """config[0] (32x32; and the calibrated checkpoint at 32x32 and 64x96) against the reference's own CPU forward
+    (tests/golden/net_*.npz): encoder features within 1e-5, symbols identical except provable quantiser near-ties, P within 1e-5
+    -- through get_P on the reference's bottlenecks, so that a flipped symbol cannot void the comparison -- and per-scale bpsp
+    within 1e-4 relative (+ 16 bits per flipped symbol)."""
+    cfg, sd = l3c_checkpoint(calibrated)
+    blueprint = blueprints(calibrated)
+    g = golden(fixture)
+    st = int(g['p0_stride']) if 'p0_stride' in g.files else 1
     img = torch.from_numpy(g['img'].astype(np.float32)).cuda()
     out = blueprint.forward(img)
     levels = sd['nets.0.enc.levels'].numpy()
     assert torch.equal(out.S[0].cpu(), torch.from_numpy(g['S0'].astype(np.int64)))
     flips = 0
     for s in range(3):
-        flips += _symbols_equal_up_to_near_ties(out.S[s + 1].cpu().numpy(), g['S%d' % (s + 1)], g['enc_bn%d' % s], levels)
+        flips += _symbols_equal_up_to_near_ties(out.S[s + 1].cpu().numpy(), g['S%d' % (s + 1)], g['enc_bn%d' % s], levels,
+                                                tol=(5e-4 if calibrated else 5e-5))
+        if 'enc_F%d' % s not in g.files:
+            continue
         Fe = out.raw.F_enc[s].cpu().permute(0, 3, 1, 2).numpy()
         err = np.abs(Fe - g['enc_F%d' % s]).max()
         print('scale {}: max |F_enc - reference| = {:.3g}'.format(s, err))
-        assert err < TOL_F, (s, err)
+        assert err < _tol(g['enc_F%d' % s], TOL_F), (s, err)
     f_prev = None
     for s in (2, 1, 0):
         P, f_prev = blueprint.net.get_P(s, torch.from_numpy(g['bn%d' % (s + 1)]).cuda(), f_prev)
-        assert P.shape == g['P%d' % s].shape
-        err = np.abs(P.cpu().numpy() - g['P%d' % s]).max()
-        print('scale {}: max |P - reference| = {:.3g}'.format(s, err))
-        assert err < TOL_P, (s, err)
+        Pn = P.cpu().numpy()
+        if s == 0:
+            Pn = Pn[:, :, ::st, ::st]
+        assert Pn.shape == g['P%d' % s].shape
+        err = np.abs(Pn - g['P%d' % s]).max()
+        print('scale {}: max |P - reference| = {:.3g} (largest |P| {:.3g})'.format(s, err, np.abs(g['P%d' % s]).max()))
+        assert err < _tol(g['P%d' % s], TOL_P), (s, err)
         if flips == 0:
             assert torch.equal(P, out.P[s]), s            # and the forward pass computed exactly this
     loss = blueprint.get_loss(out)
     got = np.array([float(b) for b in loss.nonrecursive_bpsps])
     assert np.allclose(got, g['bpsp'], rtol=1e-4, atol=16.0 * flips / img.numel()), (got, g['bpsp'], flips)
+    if calibrated:
+        assert sum(got) < 10.5
     assert out.L == [256, 25, 25, 25] and out.bn[0] is None
     for s in range(1, 4):
         assert torch.equal(out.bn[s].cpu(), torch.from_numpy(levels)[out.S[s].cpu()])
 
 
-def test_decoder_side_on_reference_bottlenecks(golden, blueprint):
-    """get_P fed with the REFERENCE's bn_q (so no quantiser flip can leak in): F and P within 1e-5."""
-    g = golden('net_32.npz')
+@pytest.mark.parametrize('fixture,calibrated', NET_FIXTURES[:2])
+def test_decoder_side_on_reference_bottlenecks(golden, blueprints, fixture, calibrated):
+    """get_P fed with the REFERENCE's bn_q (so no quantiser flip can leak in): F and P within 1e-5 (relative)."""
+    g = golden(fixture)
+    blueprint = blueprints(calibrated)
     f_prev = None
     for s in (2, 1, 0):
         bn = torch.from_numpy(g['bn%d' % (s + 1)]).cuda()
         P, f_prev = blueprint.net.get_P(s, bn, f_prev)
-        assert np.abs(f_prev.cpu().numpy() - g['dec_F%d' % s]).max() < TOL_F, s
-        assert np.abs(P.cpu().numpy() - g['P%d' % s]).max() < TOL_P, s
+        assert np.abs(f_prev.cpu().numpy() - g['dec_F%d' % s]).max() < _tol(g['dec_F%d' % s], TOL_F), s
+        assert np.abs(P.cpu().numpy() - g['P%d' % s]).max() < _tol(g['P%d' % s], TOL_P), s
 
 
+@pytest.mark.parametrize('calibrated', [False, True])
 @pytest.mark.parametrize('H,W', [(40, 56), (64, 96), (8, 8), (104, 200)])
-def test_forward_vs_oracle_other_sizes(blueprint, synthetic_l3c, H, W):
+def test_forward_vs_oracle_other_sizes(blueprints, l3c_checkpoint, H, W, calibrated):
     """Other sizes against the oracle: the encoder chain (which never sees the symbols: enc.feed_F) from the forward pass, the
     decoder chain and P through get_P on the ORACLE's bottlenecks; a flipped near-tie symbol is counted, never skipped."""
     from l3c_pytorch_amd.helpers import synthetic
-    cfg, sd = synthetic_l3c
+    cfg, sd = l3c_checkpoint(calibrated)
+    blueprint = blueprints(calibrated)
     img = synthetic.make_image(H, W, 5, 'natural').unsqueeze(0).float()
     with torch.no_grad():
         ref = onet.forward(img, sd)
@@ -99,20 +136,23 @@ def test_forward_vs_oracle_other_sizes(blueprint, synthetic_l3c, H, W):
     levels = sd['nets.0.enc.levels'].numpy()
     flips = 0
     for s in range(3):
-        flips += _symbols_equal_up_to_near_ties(out.S[s + 1].cpu().numpy(), ref.S[s + 1].numpy(), bn_ref[s], levels)
-        assert (out.raw.F_enc[s].cpu().permute(0, 3, 1, 2) - ref.F_enc[s]).abs().max() < TOL_F, s
+        flips += _symbols_equal_up_to_near_ties(out.S[s + 1].cpu().numpy(), ref.S[s + 1].numpy(), bn_ref[s], levels,
+                                                tol=(5e-4 if calibrated else 5e-5))
+        assert (out.raw.F_enc[s].cpu().permute(0, 3, 1, 2) - ref.F_enc[s]).abs().max() < _tol(ref.F_enc[s], TOL_F), s
     f_prev = None
     for s in (2, 1, 0):
         P, f_prev = blueprint.net.get_P(s, ref.bn[s + 1].cuda(), f_prev)
-        assert (f_prev.cpu() - ref.F_dec[s]).abs().max() < TOL_F, s
-        assert (P.cpu() - ref.P[s]).abs().max() < TOL_P, s
+        assert (f_prev.cpu() - ref.F_dec[s]).abs().max() < _tol(ref.F_dec[s], TOL_F), s
+        assert (P.cpu() - ref.P[s]).abs().max() < _tol(ref.P[s], TOL_P), s
         if flips == 0:
             assert torch.equal(P, out.P[s]), s
 
 
-def test_get_P_is_bit_identical_to_forward_and_batch_invariant(blueprint):
+@pytest.mark.parametrize('calibrated', [False, True])
+def test_get_P_is_bit_identical_to_forward_and_batch_invariant(blueprints, calibrated):
     """The lossless contract (P4): the decoder recomputes P from bn_q with the same kernels and tile schedule."""
     from l3c_pytorch_amd.helpers import synthetic
+    blueprint = blueprints(calibrated)
     imgs = torch.stack([synthetic.make_image(48, 72, i, 'natural') for i in range(3)]).float().cuda()
     out = blueprint.forward(imgs)
     f_prev = None
@@ -125,11 +165,13 @@ def test_get_P_is_bit_identical_to_forward_and_batch_invariant(blueprint):
         assert torch.equal(single.S[s + 1], out.S[s + 1][1:2])
 
 
+@pytest.mark.parametrize('calibrated', [False, True])
 @pytest.mark.parametrize('H,W,B,kind', [(32, 32, 1, 'uniform'), (64, 96, 3, 'natural'), (8, 16, 2, 'smooth'),
                                         (128, 192, 2, 'natural')])
-def test_encode_decode_lossless(blueprint, H, W, B, kind):
+def test_encode_decode_lossless(blueprints, H, W, B, kind, calibrated):
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
     from l3c_pytorch_amd.helpers import synthetic
+    blueprint = blueprints(calibrated)
     imgs = torch.stack([synthetic.make_image(H, W, 10 + i, kind) for i in range(B)]).long()
     bc = Bitcoding(blueprint)
     enc = bc.encode_batch(imgs)
@@ -177,12 +219,14 @@ def test_encode_many_heterogeneous_equals_per_batch(blueprint):
         assert torch.equal(dec.cpu(), x)
 
 
-def test_file_api_with_padding_and_reference_file_size(golden, blueprint, tmp_path):
-    """reference API: encode(img, path) -> bpsp, decode(path) -> 1CHW long; odd sizes are centre padded."""
+@pytest.mark.parametrize('fixture,calibrated', NET_FIXTURES)
+def test_file_api_with_padding_and_reference_file_size(golden, blueprints, tmp_path, fixture, calibrated):
+    """reference API: encode(img, path) -> bpsp, decode(path) -> 1CHW long; odd sizes are centre padded.  The file is within
+    16 bytes of the REFERENCE's own file for the same weights and image (7111 B default 32x32; 3976 / 18210 B calibrated)."""
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
     from l3c_pytorch_amd.helpers import synthetic
-    bc = Bitcoding(blueprint, compare_with_theory=True)
-    g = golden('net_32.npz')
+    bc = Bitcoding(blueprints(calibrated), compare_with_theory=True)
+    g = golden(fixture)
     img = torch.from_numpy(g['img'].astype(np.int64))
     p = str(tmp_path / 'a.l3c')
     bpsp = bc.encode(img, p)
