@@ -51,6 +51,9 @@ def parse_args(argv=None):
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', choices=('headline', 'dataset', 'large'), default='headline')
     ap.add_argument('--batch', type=int, default=128, help='headline: images per GPU per step')
+    ap.add_argument('--checkpoint', choices=('calibrated', 'default'), default='calibrated',
+                    help='synthetic checkpoint: calibrated = fitted probability heads (live model, ~6 bpsp); default = seeded default '
+                         'init (R and G streams at the 16-bit probability floor: the coder\'s worst case, 16.2 bpsp)')
     ap.add_argument('--images', type=int, default=500, help='dataset: images in the set (all ranks together)')
     ap.add_argument('--max-batch', type=int, default=16, help='dataset: images of one padded shape per forward pass')
     ap.add_argument('--coder-cus', type=int, default=0, help='compute units reserved for the range coder (0 = share all CUs)')
@@ -67,13 +70,13 @@ def parse_args(argv=None):
     return a
 
 
-def build_path(ms_config='cr', coder_cus=0):
+def build_path(ms_config='cr', coder_cus=0, calibrated=True):
     import l3c_pytorch_amd  # noqa: F401
     from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
     from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
     from l3c_pytorch_amd.helpers import config_parser, synthetic
     cfg = config_parser.parse_builtin('ms', ms_config)
-    sd = synthetic.make_state_dict(cfg, 0)
+    sd = synthetic.make_state_dict(cfg, 0, calibrated=calibrated)
     bp = MultiscaleBlueprint(cfg)
     bp.net.load_state_dict(sd, strict=True)
     bp.set_eval()
@@ -185,13 +188,15 @@ def roofline_leg(records, args, elapsed):
     flops, secs, n, nbytes = by[dom]
     all_f = sum(v[0] for v in by.values())
     all_s = sum(v[1] for v in by.values())
-    # Winograd F(2x2,3x3) executes 16 multiplications per 2x2 output tile and channel pair where the direct form needs 36
-    executed = 16.0 / 36.0 if dom.startswith('conv_wino') else 1.0
+    # Winograd F(2x2,3x3) executes 16 multiplications per 2x2 output tile and channel pair where the direct form needs 36;
+    # F(4x4,3x3) 36 per 4x4 tile where the direct form needs 144
+    executed = 0.25 if dom.startswith('conv_wino4') else 16.0 / 36.0 if dom.startswith('conv_wino') else 1.0
     ach = flops * executed / secs / 1e12
     roof = {'bound': 'mfma', 'kernel': dom, 'achieved': round(ach, 2), 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-            'note': ('achieved = FLOPs the matrix pipe executes (Winograd F(2x2,3x3): 16/36 of the direct convolution\'s) / HIP-event time '
-                     'of the launches in the timed region; peak = dense fp32 MFMA at 2.4 GHz' if executed < 1 else
+            'note': ('achieved = FLOPs the matrix pipe executes (Winograd {}: {} of the direct convolution\'s) / HIP-event time '
+                     'of the launches in the timed region; peak = dense fp32 MFMA at 2.4 GHz'.format(
+                         'F(4x4,3x3)' if executed == 0.25 else 'F(2x2,3x3)', '36/144' if executed == 0.25 else '16/36') if executed < 1 else
                      'implicit GEMM: algorithmic = executed FLOPs'),
             'algorithmic_tflops': round(flops / secs / 1e12, 2), 'algorithmic_frac': round(flops / secs / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
             'launches': n, 'avg_launch_us': round(secs / n * 1e6, 2), 'algorithmic_gflop_per_launch': round(flops / n / 1e9, 3),
@@ -275,7 +280,7 @@ def decode_leg(bc, enc, imgs, compute_stream):
 
 
 def run_headline(args, ranks):
-    cfg, sd, bp, bc, synthetic = build_path('cr', args.coder_cus)
+    cfg, sd, bp, bc, synthetic = build_path('cr', args.coder_cus, args.checkpoint == 'calibrated')
     from l3c_pytorch_amd import _lib, ops
     B = args.batch
     # synthetic images (seed = global image index), resident in HBM before the timed region
@@ -318,7 +323,7 @@ def run_headline(args, ranks):
             args, ranks, value, elapsed,
             config={'workload': 'L3C 0306_0001 (cr.cf, synthetic seeded checkpoint), batch of 768x512 synthetic RGB per GPU: net forward + '
                                 'fused logistic-mixture CDF head + HIP range coder -> bytes in HBM',
-                    'batch_per_gpu': B, 'image': '768x512', 'coder_cus': args.coder_cus, 'sharding': 'images, replicas only (no collective)'},
+                    'checkpoint': args.checkpoint, 'batch_per_gpu': B, 'image': '768x512', 'coder_cus': args.coder_cus, 'sharding': 'images, replicas only (no collective)'},
             bpsp=round(bits / subpx, 4), flop_per_px=ALGO_FLOP_PER_PX,
             end_to_end_algorithmic_tflops=round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / ranks.world, 2),
             device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1),
@@ -331,7 +336,7 @@ def run_headline(args, ranks):
 
 def run_dataset(args, ranks):
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')       # (read at HIP start-up; set by main() before the first HIP call)
-    cfg, sd, bp, bc, synthetic = build_path('cr', args.coder_cus)
+    cfg, sd, bp, bc, synthetic = build_path('cr', args.coder_cus, args.checkpoint == 'calibrated')
     from l3c_pytorch_amd import _lib
     from l3c_pytorch_amd.helpers import dataset_codec, pad, sharding
     sizes = dataset_codec.draw_sizes(args.images)
@@ -371,7 +376,7 @@ def run_dataset(args, ranks):
 
 
 def run_large(args, ranks):
-    cfg, sd, bp, bc, synthetic = build_path('cr_rgb_shared', 0)
+    cfg, sd, bp, bc, synthetic = build_path('cr_rgb_shared', 0, args.checkpoint == 'calibrated')
     from l3c_pytorch_amd import _lib, auto_crop
     from l3c_pytorch_amd.helpers import pad
     recurse = 3

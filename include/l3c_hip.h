@@ -252,6 +252,19 @@ int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *pa
 int l3c_conv_wino(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 int l3c_conv_wino_set_tiles_per_block(int n);
 /*
+ * The same convolution by Winograd F(4x4, 3x3) (interpolation points 0, +-1, +-2, inf): 4x fewer multiplications than the direct
+ * form, 1.78x fewer than F(2x2, 3x3); the 36 per-position GEMMs on v_mfma_f32_16x16x4_f32, output transform in registers.
+ * `packed_w` must come from l3c_conv_wino4_pack_weights (G g G^T computed in double precision, l3c_conv_wino4_packed_words(Cout,
+ * Cin) floats).  Replaces the same cuDNN call sites as l3c_conv_wino (modules/edsr.py:63-89, net.py:136-148, :173-184,
+ * prob_clf.py:71-74); differs from the direct convolution by fp32 rounding (measured: the L3C forward stays within 5e-6 of the
+ * fp32 reference relative to each tensor's largest magnitude, profiles/r03_wino_f43_numerics.log).  Cin % 16 == 0; input and
+ * packed weights 16-byte aligned, input channel stride / offset multiples of 4; output / residual: any channel slice.
+ */
+int64_t l3c_conv_wino4_packed_words(int Cout, int Cin);
+int l3c_conv_wino4_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
+int l3c_conv_wino4(const l3c_conv_desc *desc_host, l3c_stream_t stream);
+int l3c_conv_wino4_set_tiles_per_block(int n);
+/*
  * Pointwise (KS == 1, stride 1) convolution Cin -> Cout <= 160 as a pixel x channel GEMM on the fp32 MFMA: the 192 -> Kp layer that
  * ends every probability classifier (reference prob_clf.py:71-74).  `packed_w` must come from l3c_conv_pw_pack_weights
  * (l3c_conv_pw_packed_words(Cout, Cin) floats).  Cin % 64 == 0; bias only (epilogue == 0); input / weights 16-byte aligned and

@@ -10,13 +10,13 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_wino.hip', 'conv_pw.hip']
+SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_wino.hip', 'conv_pw.hip', 'conv_wino4.hip']
 HEADERS = ['ac_core.h', 'l3c_common.h', os.path.join('..', '..', 'include', 'l3c_hip.h')]
 LIB = os.path.join(HERE, 'libl3c_hip.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 # per-source flags.  The MFMA kernels: no SLP vectorisation -- hipcc otherwise packs adjacent scalar fp32 adds of the input
 # transform into v_pk_add_f32 / v_pk_fma_f32, which beside MFMAs cost more issue time than the plain instructions they replace.
-SOURCE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_pw.hip': ['-fno-slp-vectorize']}
+SOURCE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_pw.hip': ['-fno-slp-vectorize'], 'conv_wino4.hip': ['-fno-slp-vectorize']}
 
 
 def _stale(target, deps):

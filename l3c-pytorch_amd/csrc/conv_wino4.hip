@@ -1,0 +1,571 @@
+// conv_wino4.hip -- 3x3 / stride 1 convolution (dilation 1, 2, 4) by Winograd F(4x4, 3x3) on the fp32 MFMA.
+//
+// 4x fewer multiplications than the direct form and 1.78x fewer than F(2x2,3x3) (conv_wino.hip): every 4x4 output tile is
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A,        d the 6x6 input tile, interpolation points {0, +-1, +-2, inf}:
+//     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// The sum over input channels is, for each of the 36 positions (xi, nu) of the transformed tile, a GEMM
+//     M[xi,nu] (tiles x Cout) = V[xi,nu] (tiles x Cin) * U[xi,nu] (Cin x Cout)
+// on v_mfma_f32_16x16x4_f32.  fp32 throughout; the error against the direct convolution was measured BEFORE the kernel was
+// written (tests/numerics/wino_f43_numerics.py -> profiles/r03_wino_f43_numerics.log: the whole L3C forward with this algorithm
+// in fp32 stays within 5e-6 of the fp32 oracle relative to each tensor's largest magnitude; north_star allows 1e-5).
+//
+//   * block = 256 threads = 4 wavefronts on a 16 x 16 output tile = 4 x 4 Winograd tiles, 64 output channels.  Wavefront w
+//     owns ALL 36 positions of the 16 tiles for 16 output channels: 36 accumulator fragments of 4 registers = 144 registers
+//     (D layout of the 16x16 MFMA: lane = output channel, lane / 16 = tile row, register = tile column).  Every lane therefore
+//     holds complete transformed tiles and the output transform A^T M A runs in registers: no exchange, no barrier.
+//     <= 256 registers and 68 KB of LDS per block: TWO blocks per CU, the matrix pipe runs one block's MFMAs while the other
+//     is in its prologue, at its chunk barrier or in its output transform (the lesson of conv_wino.hip);
+//   * input channels in chunks of 8 = two k-steps of the MFMA.  The raw 18 x 18 patch of chunk g + 3 is being fetched into
+//     registers (buffer descriptor over the image: zero padding = the range check), the patch of g + 2 stored to LDS, the
+//     one of g + 1 transformed by all 256 threads (thread = tile x channel x half of the rows xi; bank-conflict-free) into
+//     the other V buffer WHILE the 72 MFMAs of chunk g run; ONE barrier per chunk;
+//   * V in LDS as [position pair][tile][k group][position of the pair][2 channels]: one ds_read_b128 per lane feeds the four
+//     MFMAs of a position pair; the pre-transformed weights U (l3c_conv_wino4_pack_weights, the same fragment order) never
+//     touch LDS: one 16-byte buffer load per lane and position pair straight into the B operands, four pairs ahead;
+//   * the bias rides in the accumulator of position (1, 1): column 1 of A^T is all ones, so M[1][1] enters all 16 outputs of
+//     a tile with weight 1;
+//   * a block walks up to 6 horizontally adjacent tiles over ONE chunk pipeline (the fetches the last chunks of a tile issue
+//     are the first patches of the next tile).
+// A dilated conv is the dense conv on each of the dil x dil interleaved sub-grids of the image (strided indexing).
+#include "l3c_common.h"
+
+#include <stdlib.h>
+
+#include <atomic>
+#include <type_traits>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// n / d for 0 <= n < 2^31 as a multiplication (Granlund-Montgomery)
+struct W4Div {
+    unsigned m, sh;   // d == 1: m = 0
+    __device__ __forceinline__ unsigned div(unsigned n) const { return m ? __umulhi(n, m) >> sh : n; }
+};
+static W4Div w4_div(unsigned d) {
+    W4Div r{0, 0};
+    if (d <= 1) return r;
+    unsigned L = 0;
+    while ((1ull << L) < d) ++L;
+    r.m = (unsigned)(((1ull << (31 + L)) / d) + 1);
+    r.sh = L - 1;
+    return r;
+}
+
+struct Wino4Params {
+    const float *in;
+    const float *u;
+    const float *bias;
+    const float *res;
+    float *out;
+    int in_cstride, in_coff, res_cstride, res_coff, out_cstride, out_coff;
+    int B, H, W, Cin, Cout;
+    int dil, dil_log2;
+    W4Div div_groups, div_groups_x, div_chunks;
+    int tiles_x, tiles_y, n_chunks_o, total_blocks;
+    int tpb, groups_x;
+};
+
+constexpr int OT = 16;                          // output tile of a block: 4 x 4 Winograd tiles of 4 x 4 pixels
+constexpr int PW = OT + 2;                      // input patch side
+constexpr int CK = 8;                           // input channels per chunk
+constexpr int NPP = 18;                         // position pairs: pp = xi * 3 + nu / 2
+constexpr int PSR = 12;                         // LDS stride of a raw patch pixel (floats): 4 * PSR * tx covers distinct banks
+constexpr int RAW_FLOATS = PW * PW * PSR;       // 3888
+constexpr int VPP = 16 * 16;                    // floats of one position pair in V: [16 tiles][4 k groups][2 positions][2 channels]
+constexpr int V_FLOATS = NPP * VPP;             // 4608
+constexpr int U_CHUNK_FLOATS = NPP * 4 * 64 * 4;   // packed weights of one input chunk x one 64-channel output chunk
+constexpr int V_OFF0 = 0, V_OFF1 = V_FLOATS, RAW_OFF0 = 2 * V_FLOATS, RAW_OFF1 = 2 * V_FLOATS + RAW_FLOATS;
+constexpr int LDS_MAIN_FLOATS = 2 * V_FLOATS + 2 * RAW_FLOATS;
+constexpr int WIN_FLOATS = 4 * 80;              // output window of a wavefront: [4 tile rows][16 pixels + 4 of padding][16 channels]
+constexpr int LDS_FLOATS = LDS_MAIN_FLOATS + 4 * 2 * WIN_FLOATS;
+constexpr int W4_LDS_BYTES = LDS_FLOATS * 4;    // 78 208: two blocks per CU
+constexpr int W4_TPB_MAX = 6;
+constexpr int OOB = 0x7ffffff0;                 // a byte offset beyond every buffer: the access is dropped by the range check
+constexpr int N_PIECES = PW * PW * 2;           // 16-byte pieces of a patch (a pixel's 8 channels = 2 pieces)
+constexpr int NIT = (N_PIECES + 255) / 256;     // 3
+
+__device__ __forceinline__ int xcd_remap4(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
+// one 6-vector through B^T (rows of the input transform), all six outputs
+__device__ __forceinline__ void bt6(const float (&w)[6], float (&o)[6]) {
+    o[0] = __builtin_fmaf(4.0f, w[0], __builtin_fmaf(-5.0f, w[2], w[4]));
+    const float a = __builtin_fmaf(-4.0f, w[2], w[4]), b = __builtin_fmaf(-4.0f, w[1], w[3]);
+    o[1] = a + b;
+    o[2] = a - b;
+    const float c = w[4] - w[2], d = w[3] - w[1];
+    o[3] = __builtin_fmaf(2.0f, d, c);
+    o[4] = __builtin_fmaf(-2.0f, d, c);
+    o[5] = __builtin_fmaf(4.0f, w[1], __builtin_fmaf(-5.0f, w[3], w[5]));
+}
+
+// one 6-vector through A^T (output transform), four outputs
+__device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
+    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
+    y[0] = (m0 + s1) + s2;
+    y[1] = __builtin_fmaf(2.0f, d2, d1);
+    y[2] = __builtin_fmaf(4.0f, s2, s1);
+    y[3] = __builtin_fmaf(8.0f, d2, d1) + m5;
+}
+
+// Development probes (csrc/build.py --variant NAME "-DL3C_W4_PROBE=N"; results are WRONG, only the time means something): bit 0 no
+// patch fetch, 1 no input transform, 2 no weight loads inside the loop, 3 no chunk barrier, 4 no output transform / stores (one
+// store per tile keeps the accumulators alive), 5 no patch stores to LDS.  Never defined in the product build.
+#ifndef L3C_W4_PROBE
+#define L3C_W4_PROBE 0
+#endif
+
+template <bool RELU, bool RES, bool SHUFFLE>
+__global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_cc = p.Cin / CK;
+
+    // block -> (image, output-channel chunk, sub-grid, tile row, group of tiles)
+    unsigned w = (unsigned)xcd_remap4(blockIdx.x, p.total_blocks);
+    const unsigned groups = (unsigned)(p.groups_x * p.tiles_y);
+    const unsigned w_t = p.div_groups.div(w);
+    const unsigned grp = w - w_t * groups;
+    w = w_t;
+    const int dl = p.dil_log2, dil = 1 << dl;
+    const int phase = (int)(w & ((1u << (2 * dl)) - 1));
+    w >>= 2 * dl;
+    const int b = (int)p.div_chunks.div(w);
+    const int chunk_o = (int)(w - (unsigned)b * (unsigned)p.n_chunks_o);
+    const int py = phase >> dl, px = phase & (dil - 1);
+    const unsigned t_y = p.div_groups_x.div(grp);
+    const int sy0 = (int)t_y * OT;                                         // tile row origin in sub-grid coordinates
+    const int tx_first = (int)(grp - t_y * (unsigned)p.groups_x) * p.tpb;  // first tile of this block
+    const int n_t = min(p.tpb, p.tiles_x - tx_first);
+
+    // ---- patch fetch: piece i = tid + 256 it -> pixel i / 2 of the 18 x 18 patch, channels 4 (i & 1) .. + 3 of the chunk
+    int patch_off[NIT];
+    auto set_patch_tile = [&](int t) {
+        const int x0 = px + dil * ((tx_first + t) * OT - 1);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256;
+            const int c4 = i & 1, pix = i >> 1;
+            const int r = pix / PW, ci = pix - r * PW;
+            const int iy = py + dil * (sy0 - 1 + r), ix = x0 + dil * ci;
+            const bool ok = i < N_PIECES && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            patch_off[it] = ok ? ((iy * p.W + ix) * p.in_cstride + c4 * 4) * 4 : OOB;
+        }
+    };
+    int pf_tile = 0, pf_cc = 0;   // the prefetch pointer: (tile, chunk) of the next patch to fetch
+    auto pf_advance = [&]() {
+        if (++pf_cc == n_cc) {
+            if (pf_tile + 1 < n_t) {
+                pf_cc = 0;
+                set_patch_tile(++pf_tile);
+            } else {
+                pf_cc = n_cc - 1;   // past the block's last chunk: the loads stay unconditional, their data is never used
+            }
+        }
+    };
+    const auto in_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(p.in + (size_t)b * p.H * p.W * p.in_cstride + p.in_coff), 0, p.H * p.W * p.in_cstride * 4, 0x00020000);
+    f32x4 stage[NIT];
+    auto fetch_piece = [&](int it) {
+        if constexpr (L3C_W4_PROBE & 1) return;
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], pf_cc * CK * 4, 0));
+    };
+    auto store_piece = [&](float *dst, int it, const f32x4 &v) {
+        const int i = tid + it * 256;
+        if (it < NIT - 1 || i < N_PIECES) *reinterpret_cast<f32x4 *>(&dst[(i >> 1) * PSR + (i & 1) * 4]) = v;
+    };
+
+    // ---- B operands: uniform descriptor + fixed per-lane byte offset + scalar offset; all loads unconditional
+    const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u + (size_t)chunk_o * n_cc * U_CHUNK_FLOATS), 0,
+                                                          n_cc * U_CHUNK_FLOATS * 4, 0x00020000);
+    const int u_lane = (wave * 64 + lane) * 16;
+    f32x4 b_ring[4];
+    auto fetch_b = [&](int cc, int pp) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (cc * NPP + pp) * (4 * 64 * 16), 0));
+    };
+
+    // ---- input transform roles: thread = (tile (ty, tx), channel c, half TH of the rows xi)
+    const int t_c = lane & 7, t_tx = (lane >> 3) & 3, t_ty = (wave & 1) * 2 + (lane >> 5), t_h = wave >> 1;
+    const int t_src = ((4 * t_ty + t_h) * PW + 4 * t_tx) * PSR + t_c;
+    const int t_dst = (t_ty * 4 + t_tx) * 16 + (t_c >> 1) * 4 + (t_c & 1) + (3 * t_h) * 3 * VPP;
+
+    // ---- A fragments: lane (tile m = lane & 15, k group lane >> 4)
+    const int a_lane = (lane & 15) * 16 + (lane >> 4) * 4;
+    f32x4 a_ring[2];
+
+    f32x4 acc[36];
+    const int co_lane = chunk_o * 64 + wave * 16 + (lane & 15);
+    const float bias_init = co_lane < p.Cout ? p.bias[co_lane] : 0.0f;
+
+    // ---- output addressing: ONE uniform descriptor at the block's first output row, a per-lane byte offset, uniform offsets
+    constexpr int S = SHUFFLE ? 2 : 1;
+    const int col_b = S * dil * p.out_cstride * 4, row_b = S * dil * (S * p.W) * p.out_cstride * 4;   // one conv pixel / row on
+    const int rcol_b = dil * p.res_cstride * 4, rrow_b = dil * p.W * p.res_cstride * 4;
+    const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * px) * p.out_cstride + p.out_coff +
+            (SHUFFLE ? chunk_o * 16 : chunk_o * 64), 0, OOB, 0x00020000);
+    const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(RES ? p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px) * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias),
+        0, RES ? OOB : 0, 0x00020000);
+
+    auto body = [&](auto th_c) __attribute__((always_inline)) {
+        constexpr int TH = decltype(th_c)::value;
+        float T[3][6];    // rows xi = 3 TH .. 3 TH + 2 of B^T d for this thread's (tile, channel)
+        float L[5];       // raw rows TH .. TH + 4 of one patch column
+        auto tr_load = [&](const float *src, int col) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) L[i] = src[(i * PW + col) * PSR];
+        };
+        auto tr_col = [&](int col) {
+            const float(&l)[5] = L;
+            const float x = __builtin_fmaf(4.0f, l[0], __builtin_fmaf(-5.0f, l[2], l[4]));
+            if constexpr (TH == 0) {   // xi = 0, 1, 2 from raw rows 0 .. 4
+                const float a = __builtin_fmaf(-4.0f, l[2], l[4]), bb = __builtin_fmaf(-4.0f, l[1], l[3]);
+                T[0][col] = x;
+                T[1][col] = a + bb;
+                T[2][col] = a - bb;
+            } else {                   // xi = 3, 4, 5 from raw rows 1 .. 5 (l[i] = row 1 + i)
+                const float a = l[3] - l[1], d = l[2] - l[0];
+                T[0][col] = __builtin_fmaf(2.0f, d, a);
+                T[1][col] = __builtin_fmaf(-2.0f, d, a);
+                T[2][col] = x;
+            }
+        };
+        float R[6];
+        auto tr_row = [&](int k) { bt6(T[k], R); };
+        auto tr_write = [&](float *dst, int k) {   // row xi = 3 TH + k: positions (xi, 0..5) = pairs 3 xi .. 3 xi + 2
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                dst[(3 * k + j) * VPP] = R[2 * j];
+                dst[(3 * k + j) * VPP + 2] = R[2 * j + 1];
+            }
+        };
+
+        // ---- prologue: patches 0, 1 -> raw[0], raw[1]; patch 2 in flight; V[0] = transform of patch 0; B of the first pairs
+        set_patch_tile(0);
+        {
+            f32x4 first[2][NIT];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+#pragma unroll
+                for (int it = 0; it < NIT; ++it)
+                    first[k][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], pf_cc * CK * 4, 0));
+                pf_advance();
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) fetch_piece(it);
+            pf_advance();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b_ring[q] = fetch_b(0, q);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) store_piece(lds + RAW_OFF0, it, first[0][it]);
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) store_piece(lds + RAW_OFF1, it, first[1][it]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int col = 0; col < 6; ++col) {
+            tr_load(lds + RAW_OFF0 + t_src, col);
+            tr_col(col);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            tr_row(k);
+            tr_write(lds + V_OFF0 + t_dst, k);
+        }
+        __syncthreads();
+        a_ring[0] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane);
+        a_ring[1] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane + VPP);
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): nothing of the prologue stays in flight (see conv_wino.hip)
+
+        // Chunk g (buffer parity par = g & 1) -- invariants at its start: V[par] complete and visible; raw[par ^ 1] = patch of
+        // chunk g + 1, visible; `stage` = patch of chunk g + 2 (in flight); b_ring = B of pairs 0..3 (in flight); a_ring = A of
+        // pairs 0, 1; the prefetch pointer is at chunk g + 3.
+        auto chunk = [&](const int cc, auto first_c, auto par_c) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
+            constexpr int par = decltype(par_c)::value;
+            const int cc_b = cc + 1 == n_cc ? 0 : cc + 1;   // the next chunk's weights (the next tile starts over with chunk 0)
+            const float *a_cur = lds + (par ? V_OFF1 : V_OFF0) + a_lane;
+            const float *a_nxt = lds + (par ? V_OFF0 : V_OFF1) + a_lane;
+            float *v_next = lds + (par ? V_OFF0 : V_OFF1) + t_dst;
+            const float *r_src = lds + (par ? RAW_OFF0 : RAW_OFF1) + t_src;   // raw[par ^ 1]
+            float *r_dst = lds + (par ? RAW_OFF1 : RAW_OFF0);                 // raw[par]
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#define L3C_W4_MFMA(Q, A, B, ZERO)                                                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (FIRST && (ZERO) && (Q) != 7) ? zero4 : acc[Q], 0, 0, 0); \
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int pp = 0; pp < NPP; ++pp) {
+                const f32x4 &A = a_ring[pp & 1];
+                const f32x4 &Bv = b_ring[(pp + 2 * par) & 3];   // 18 pairs per chunk: the ring position shifts by 2 per chunk
+                if (pp == NPP - 1) {
+                    // everything chunk g + 1 needs from this wave is issued: V[par ^ 1] written, patch g + 2 stored
+                    if constexpr (!(L3C_W4_PROBE & 8)) __syncthreads();
+                    a_ring[0] = *reinterpret_cast<const f32x4 *>(a_nxt);
+                }
+                L3C_W4_MFMA(2 * pp, A[0], Bv[0], true)
+                constexpr bool TR = !(L3C_W4_PROBE & 2), ST = !(L3C_W4_PROBE & 32);
+                if (TR && pp < 6) tr_load(r_src, pp);
+                if (TR && (pp == 7 || pp == 9 || pp == 11)) tr_row((pp - 7) >> 1);
+                if (ST && pp == 13) store_piece(r_dst, 0, stage[0]);
+                if (pp == 14) fetch_piece(0);
+                L3C_W4_MFMA(2 * pp + 1, A[2], Bv[2], true)
+                if (TR && (pp == 8 || pp == 10 || pp == 12)) tr_write(v_next, (pp - 8) >> 1);
+                if (ST && pp == 13) store_piece(r_dst, 1, stage[1]);
+                if (pp == 14) fetch_piece(1);
+                L3C_W4_MFMA(2 * pp, A[1], Bv[1], false)
+                if (TR && pp < 6) tr_col(pp);
+                if (ST && pp == 13) store_piece(r_dst, 2, stage[2]);
+                if (pp == 14) fetch_piece(2);
+                if (pp == 15) pf_advance();
+                L3C_W4_MFMA(2 * pp + 1, A[3], Bv[3], false)
+                if (pp < NPP - 2) a_ring[pp & 1] = *reinterpret_cast<const f32x4 *>(a_cur + (pp + 2) * VPP);
+                if (pp == NPP - 1) a_ring[1] = *reinterpret_cast<const f32x4 *>(a_nxt + VPP);
+                if constexpr (!(L3C_W4_PROBE & 4)) b_ring[(pp + 2 * par) & 3] = pp + 4 < NPP ? fetch_b(cc, pp + 4) : fetch_b(cc_b, pp + 4 - NPP);
+            }
+#undef L3C_W4_MFMA
+        };
+
+        for (int t = 0; t < n_t; ++t) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {   // (volatile: four copies made here, per tile -- not four registers held forever)
+                float v;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(bias_init));
+                acc[7][r] = v;
+            }
+            chunk(0, std::true_type{}, std::integral_constant<int, 0>{});
+            chunk(1, std::false_type{}, std::integral_constant<int, 1>{});
+            for (int cc = 2; cc < n_cc; cc += 2) {
+                chunk(cc, std::false_type{}, std::integral_constant<int, 0>{});
+                chunk(cc + 1, std::false_type{}, std::integral_constant<int, 1>{});
+            }
+
+            // ---- output transform Y = A^T M A, in registers: lane (q = lane >> 4, n = lane & 15) holds, in register r of the 36
+            // fragments, the transformed tile (ty, tx) = (q, r) of output channel n.  The results leave through a small
+            // wavefront-private LDS window that turns "one channel, 16 pixels per lane" into "four adjacent channels of one pixel
+            // per lane": round (r, i) = output row i of the four tiles (., r) -> 16 pixels x 16 channels: four ds_write_b32, one
+            // ds_read_b128, one 16-byte store (and residual load) per lane -- 16 of each per tile instead of 64 four-byte ones.
+            const int q = lane >> 4, n = lane & 15;
+            const int q2 = lane >> 4, j2 = (lane >> 2) & 3, c4 = lane & 3;   // store layout: pixel (4 q2 + i, 4 r + j2), channels 4 c4 ..
+            const int sx0 = (tx_first + t) * OT;
+            const bool lane_ok = chunk_o * 64 + wave * 16 + (SHUFFLE ? 0 : c4 * 4) < p.Cout;   // Cout % 4 (shuffle: % 16) == 0
+            int o_lane, r_lane = 0;
+            if constexpr (SHUFFLE)   // conv channel co -> output pixel (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2: lane
+                                     // (pixel, sub-pixel c4) stores the four output channels of this wavefront's 16 conv channels
+                o_lane = 4 * q2 * row_b + j2 * col_b + ((c4 >> 1) * (2 * p.W) + (c4 & 1)) * p.out_cstride * 4 + wave * 16;
+            else
+                o_lane = 4 * q2 * row_b + j2 * col_b + (wave * 16 + c4 * 4) * 4;
+            if constexpr (RES) r_lane = 4 * q2 * rrow_b + j2 * rcol_b + (wave * 16 + c4 * 4) * 4;
+            const int oy_l = py + dil * (sy0 + 4 * q2), ox_l = px + dil * (sx0 + j2);
+            // window: [q][16 + 4 pixels-worth of padding][16 channels]; pixel stride 16 floats, q stride 80 floats (banks 16 q + n)
+            float *win = lds + LDS_MAIN_FLOATS + wave * (2 * WIN_FLOATS);
+            float *w_dst = win + q * 80 + (SHUFFLE ? (n & 3) * 4 + (n >> 2) : n);   // shuffle: channels of one sub-pixel adjacent
+            const float *w_src = win + q2 * 80 + j2 * 16 + c4 * 4;
+            auto lane_off = [&](int base, int r, int i) {
+                const bool ok = lane_ok && oy_l + dil * i < p.H && ox_l + dil * 4 * r < p.W;
+                return ok ? base : OOB;
+            };
+            f32x4 resv[3];
+            auto res_load = [&](int k) {   // round k = r * 4 + i
+                if constexpr (RES)
+                    resv[k % 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                r_rsrc, lane_off(r_lane, k >> 2, k & 3), (k & 3) * rrow_b + (sx0 + 4 * (k >> 2)) * rcol_b, 0));
+            };
+            auto flush = [&](int k) {      // round k: window -> registers -> memory
+                f32x4 v = *reinterpret_cast<const f32x4 *>(w_src + (k & 1) * WIN_FLOATS);
+                if constexpr (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                }
+                if constexpr (RES) v = v + resv[k % 3];
+                const int vo = lane_off(o_lane, k >> 2, k & 3), so = (k & 3) * row_b + (sx0 + 4 * (k >> 2)) * col_b;
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
+                                                       o_rsrc, vo, so, 0);
+                // gfx950: a VALU write to the data registers of a 16-byte buffer store with a REGISTER soffset, issued right behind
+                // it, overtakes the store's read of its last dwords, and the compiler inserts no wait states for this form
+                // (found with conv_wino.hip; tools/check_store_hazard.py scans the ISA at build time)
+                asm volatile("s_nop 1");
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            if constexpr (L3C_W4_PROBE & 16) {
+                f32x4 sum = acc[0];
+#pragma unroll
+                for (int i = 1; i < 36; ++i) sum = sum + acc[i];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, sum),
+                                                       o_rsrc, lane_off(o_lane, 0, 0), sx0 * col_b, 0);
+                continue;
+            }
+            res_load(0);
+            res_load(1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float tcol[4][6];   // t[i][nu] = sum_xi A^T[i][xi] M[xi][nu]
+#pragma unroll
+                for (int nu = 0; nu < 6; ++nu) {
+                    float y[4];
+                    at6(acc[0 * 6 + nu][r], acc[1 * 6 + nu][r], acc[2 * 6 + nu][r], acc[3 * 6 + nu][r], acc[4 * 6 + nu][r], acc[5 * 6 + nu][r], y);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) tcol[i][nu] = y[i];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = r * 4 + i;
+                    float y[4];
+                    at6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], y);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w_dst[(k & 1) * WIN_FLOATS + j * 16] = y[j];
+                    // the window is this wavefront's own: its LDS operations execute in order, no block barrier (the fence keeps
+                    // the compiler from moving the reads of other lanes' values above the writes)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (k >= 1) flush(k - 1);
+                    if (k + 2 < 16) res_load(k + 2);   // (into the register quad flush(k - 1) has just released)
+                }
+            }
+            flush(15);
+        }
+    };
+    if (t_h == 0) body(std::integral_constant<int, 0>{});
+    else body(std::integral_constant<int, 1>{});
+}
+
+// OIHW 3x3 weights -> U = G g G^T (computed in double, rounded once) in the kernel's fragment order
+// [Cout/64][Cin/8][18 position pairs][4 waves][64 lanes][4]: lane (n = lane % 16, kq = lane / 16), element e * 2 + s holds
+// U[position (xi = pp / 3, nu = 2 (pp % 3) + e)][co = chunk * 64 + wave * 16 + n][ci = cc * 8 + 2 kq + s].
+__global__ __launch_bounds__(256) void pack_wino4_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ packed,
+                                                         int64_t total) {
+    const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t r = i;
+        const int idx = r % 4;  r /= 4;
+        const int lane = r % 64;  r /= 64;
+        const int wv = r % 4;  r /= 4;
+        const int pp = r % NPP;  r /= NPP;
+        const int cc = r % (Cin / 8);  r /= (Cin / 8);
+        const int chunk = (int)r;
+        const int co = chunk * 64 + wv * 16 + (lane & 15);
+        const int ci = cc * 8 + 2 * (lane >> 4) + (idx & 1);
+        const int xi = pp / 3, nu = 2 * (pp % 3) + (idx >> 1);
+        double u = 0.0;
+        if (co < Cout) {
+            const float *g = w + ((size_t)co * Cin + ci) * 9;
+            for (int a = 0; a < 3; ++a)
+                for (int c = 0; c < 3; ++c) u += G[xi][a] * (double)g[a * 3 + c] * G[nu][c];
+        }
+        packed[i] = (float)u;
+    }
+}
+
+}  // namespace
+
+static std::atomic<int> g_w4_tpb{getenv("L3C_WINO4_TPB") ? atoi(getenv("L3C_WINO4_TPB")) : 0};
+static const long long g_w4_min_blocks = getenv("L3C_WINO4_MIN_BLOCKS") ? atoll(getenv("L3C_WINO4_MIN_BLOCKS")) : 8 * 512;
+
+extern "C" {
+
+int l3c_conv_wino4_set_tiles_per_block(int n) { return g_w4_tpb.exchange(n < 0 ? 0 : n > 64 ? 64 : n); }
+
+int64_t l3c_conv_wino4_packed_words(int Cout, int Cin) { return (int64_t)((Cout + 63) / 64) * (Cin / 8) * U_CHUNK_FLOATS; }
+
+int l3c_conv_wino4_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream) {
+    L3C_REQUIRE(w_oihw && packed, "null pointer");
+    L3C_REQUIRE(Cout > 0 && Cin > 0 && Cin % 16 == 0, "Cin must be a multiple of 16");
+    const int64_t total = l3c_conv_wino4_packed_words(Cout, Cin);
+    int64_t g = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_wino4_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, l3c::as_stream(stream), w_oihw,
+                       Cout, Cin, packed, total);
+    return l3c::check_launch("pack_wino4_kernel");
+}
+
+int l3c_conv_wino4(const l3c_conv_desc *d, l3c_stream_t stream) {
+    L3C_REQUIRE(d, "null descriptor");
+    L3C_REQUIRE(d->in && d->packed_w && d->bias && d->out, "null pointer in descriptor");
+    L3C_REQUIRE(d->KS == 3 && d->stride == 1, "Winograd F(4x4,3x3): 3x3, stride 1 only");
+    L3C_REQUIRE(d->dilation == 1 || d->dilation == 2 || d->dilation == 4, "dilation must be 1, 2 or 4");
+    L3C_REQUIRE(d->dilation == 1 || !(d->epilogue & L3C_EPI_PIXEL_SHUFFLE), "pixel shuffle with dilation not provided");
+    L3C_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Cout > 0, "bad shape");
+    L3C_REQUIRE(d->Cin > 0 && d->Cin % (2 * CK) == 0, "Cin must be a multiple of 16 (an even number of 8-channel chunks)");
+    L3C_REQUIRE(d->in_cstride % 4 == 0 && d->in_coff % 4 == 0, "input channel stride/offset must be multiples of 4");
+    L3C_REQUIRE(d->out_cstride % 4 == 0 && d->out_coff % 4 == 0, "output channel stride/offset must be multiples of 4 (16-byte stores)");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || (d->res_cstride % 4 == 0 && d->res_coff % 4 == 0),
+                "residual channel stride/offset must be multiples of 4 (16-byte loads)");
+    L3C_REQUIRE(((uintptr_t)d->in | (uintptr_t)d->out | (uintptr_t)d->packed_w | ((d->epilogue & L3C_EPI_RESIDUAL) ? (uintptr_t)d->residual : 0)) % 16 == 0,
+                "input, output, residual and packed weights must be 16-byte aligned");
+    L3C_REQUIRE(d->Cout % ((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? 16 : 4) == 0,
+                "Cout must be a multiple of 4 (pixel shuffle: 16): a lane stores four adjacent channels");
+    L3C_REQUIRE((d->epilogue & ~(L3C_EPI_RELU | L3C_EPI_RESIDUAL | L3C_EPI_PIXEL_SHUFFLE)) == 0, "unknown epilogue bits");
+    L3C_REQUIRE(d->in_coff + d->Cin <= d->in_cstride, "input channel slice out of range");
+    L3C_REQUIRE(d->out_coff + ((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? d->Cout / 4 : d->Cout) <= d->out_cstride, "output channel slice out of range");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || d->residual, "residual epilogue without residual pointer");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || d->res_coff + d->Cout <= d->res_cstride, "residual channel slice out of range");
+    L3C_REQUIRE(!((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) && (d->epilogue & (L3C_EPI_RESIDUAL | L3C_EPI_RELU))),
+                "pixel shuffle + residual / ReLU not provided");
+    Wino4Params p{};
+    p.in = d->in;  p.u = d->packed_w;  p.bias = d->bias;
+    p.res = (d->epilogue & L3C_EPI_RESIDUAL) ? d->residual : nullptr;
+    p.out = d->out;
+    p.in_cstride = d->in_cstride;  p.in_coff = d->in_coff;
+    p.res_cstride = d->res_cstride;  p.res_coff = d->res_coff;
+    p.out_cstride = d->out_cstride;  p.out_coff = d->out_coff;
+    p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = d->Cin;  p.Cout = d->Cout;
+    p.dil = d->dilation;
+    p.dil_log2 = d->dilation == 4 ? 2 : d->dilation == 2 ? 1 : 0;
+    p.tiles_x = ((p.W + p.dil - 1) / p.dil + OT - 1) / OT;   // tiles of the (largest) sub-grid
+    p.tiles_y = ((p.H + p.dil - 1) / p.dil + OT - 1) / OT;
+    p.n_chunks_o = (p.Cout + 63) / 64;
+    const int64_t rows = (int64_t)p.tiles_y * p.dil * p.dil * p.n_chunks_o * p.B;
+    const int tpb_set = g_w4_tpb.load(std::memory_order_relaxed);
+    int tpb = tpb_set > 0 ? tpb_set : W4_TPB_MAX;
+    if (tpb > p.tiles_x) tpb = p.tiles_x;
+    if (tpb_set <= 0) {   // the fewest EVEN groups per tile row that still give the launch enough blocks (conv_wino.hip)
+        int g = (p.tiles_x + W4_TPB_MAX - 1) / W4_TPB_MAX;
+        while (g < p.tiles_x && rows * g < g_w4_min_blocks) ++g;
+        tpb = (p.tiles_x + g - 1) / g;
+    }
+    p.tpb = tpb;
+    p.groups_x = (p.tiles_x + tpb - 1) / tpb;
+    const int64_t total = rows * p.groups_x;
+    L3C_REQUIRE(total < (1ll << 31), "grid too large");
+    const int64_t S2 = (d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? 4 : 1;
+    L3C_REQUIRE((int64_t)p.H * p.W * p.in_cstride * 4 < 0x7ffffff0ll, "one image of the input must stay below 2 GB");
+    L3C_REQUIRE(S2 * 20 * p.dil * (p.W + 64 * p.dil) * p.out_cstride * 4 < 0x7ffffff0ll && 20ll * p.dil * (p.W + 64 * p.dil) * p.res_cstride * 4 < 0x7ffffff0ll,
+                "image too wide for 32-bit offsets inside a tile row");
+    p.total_blocks = (int)total;
+    p.div_groups = w4_div((unsigned)(p.groups_x * p.tiles_y));
+    p.div_groups_x = w4_div((unsigned)p.groups_x);
+    p.div_chunks = w4_div((unsigned)p.n_chunks_o);
+    typedef void (*kernel_t)(const Wino4Params);
+    static const kernel_t variants[5] = {conv_wino4_kernel<false, false, false>, conv_wino4_kernel<true, false, false>,
+                                         conv_wino4_kernel<false, true, false>, conv_wino4_kernel<true, true, false>,
+                                         conv_wino4_kernel<false, false, true>};
+    static bool attr_set[64][5] = {};   // > 64 KB of dynamic LDS needs the opt-in, per device
+    int dev = 0;
+    {
+        const int rc = l3c::check_hip(hipGetDevice(&dev), "hipGetDevice");
+        if (rc != L3C_OK) return rc;
+    }
+    L3C_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
+    const bool relu = d->epilogue & L3C_EPI_RELU, res = d->epilogue & L3C_EPI_RESIDUAL, shuffle = d->epilogue & L3C_EPI_PIXEL_SHUFFLE;
+    const int v = shuffle ? 4 : (relu ? 1 : 0) + (res ? 2 : 0);
+    if (!attr_set[dev][v]) {
+        const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(variants[v]),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES),
+                                      "hipFuncSetAttribute");
+        if (rc != L3C_OK) return rc;
+        attr_set[dev][v] = true;
+    }
+    hipLaunchKernelGGL(variants[v], dim3((unsigned)total), dim3(256), W4_LDS_BYTES, l3c::as_stream(stream), p);
+    return l3c::check_launch("conv_wino4_kernel");
+}
+}

@@ -11,6 +11,8 @@ from ._lib import ConvDesc, call, ptr, stream
 _CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU cross-check kernel (debugging)
 # 3x3 / stride 1 layers (dilation 1, 2, 4) run as Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) unless L3C_CONV_WINO=0
 _CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
+# ... by default in its F(4x4,3x3) form (csrc/conv_wino4.hip: 1.78x fewer multiplications again) unless L3C_CONV_WINO4=0
+_CONV_WINO4 = os.environ.get('L3C_CONV_WINO4', '1') != '0'
 # 1x1 layers with Cin % 64 == 0 and Cout <= 160 (the 192 -> Kp classifier output) run on the pointwise kernel (csrc/conv_pw.hip)
 # unless L3C_CONV_PW=0
 _CONV_PW = os.environ.get('L3C_CONV_PW', '1') != '0'
@@ -44,6 +46,11 @@ class PackedConv(object):
             n = _lib.load().l3c_conv_wino_packed_words(self.Cout, self.Cin)
             self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
             call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())
+        self.packed_wino4 = None
+        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 16 == 0:
+            n = _lib.load().l3c_conv_wino4_packed_words(self.Cout, self.Cin)
+            self.packed_wino4 = torch.empty(n, dtype=torch.float32, device='cuda')
+            call('l3c_conv_wino4_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino4), stream())
 
         self.packed_pw = None
         if _CONV_PW and self.KS == 1 and stride == 1 and self.Cin % 64 == 0 and self.Cout <= 160:
@@ -66,13 +73,32 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         out = (torch.empty(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
                else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
     impl = impl or _CONV_IMPL
-    wino = impl == 'mfma' and layer.packed_wino is not None and (layer.Cout % 16 == 0 or not pixel_shuffle)
-    if wino and H * W * cstride * 4 >= 0x7ffffff0 and layer.packed is not None:
-        wino = False     # the Winograd kernel addresses one input image with 32-bit offsets; beyond 2 GB the implicit GEMM (64-bit) takes over
-    pw = impl == 'mfma' and layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None)
+    # The Winograd kernels store / load 16 bytes per lane: channel strides and offsets of the output (and residual) slices must be
+    # multiples of 4, the pointers 16-byte aligned, Cout a multiple of 4 (pixel shuffle: 16); they address one input image with
+    # 32-bit offsets (< 2 GB) and have no pixel shuffle combined with dilation, ReLU or a residual.  Anything else goes to the
+    # implicit-GEMM kernel (64-bit addressing, 4-byte stores) -- the same preconditions l3c_conv_wino / l3c_conv_wino4 check.
+    def _aligned(t, coff):
+        return t is None or (t.shape[-1] % 4 == 0 and coff % 4 == 0 and t.data_ptr() % 16 == 0)
+    wino_ok = (layer.KS == 3 and layer.stride == 1 and _aligned(out, out_coff) and _aligned(residual, res_coff) and
+               x.data_ptr() % 16 == 0 and cstride % 4 == 0 and in_coff % 4 == 0 and H * W * cstride * 4 < 0x7ffffff0 and
+               layer.Cout % (16 if pixel_shuffle else 4) == 0 and
+               not (pixel_shuffle and (relu or residual is not None or layer.dilation != 1)))
+    # impl: 'mfma' = the product's dispatch; 'wino4' / 'wino2' / 'gemm' force one kernel (tests, probes); 'direct' = VALU cross-check
+    wino4 = (impl == 'wino4' or (impl == 'mfma' and _CONV_WINO4)) and layer.packed_wino4 is not None and wino_ok
+    wino = not wino4 and impl in ('mfma', 'wino2') and layer.packed_wino is not None and wino_ok
+    if impl in ('wino4', 'wino2'):
+        assert wino4 or wino, 'this layer / epilogue has no Winograd form'
+    if impl in ('wino4', 'wino2', 'gemm'):
+        impl = 'mfma'
+        pw_allowed = False
+    else:
+        pw_allowed = True
+    if impl == 'mfma' and not (wino or wino4) and layer.packed is None and layer.KS == 3:
+        raise _lib.L3CError('3x3 convolution outside the Winograd kernels\' preconditions and no implicit-GEMM form (Cin % 16 != 0)')
+    pw = pw_allowed and not wino4 and impl == 'mfma' and layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None)
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
-    d.packed_w = ptr(layer.packed_wino if wino else layer.packed_pw if pw else layer.packed if impl == 'mfma' else layer.weight)
+    d.packed_w = ptr(layer.packed_wino4 if wino4 else layer.packed_wino if wino else layer.packed_pw if pw else layer.packed if impl == 'mfma' else layer.weight)
     d.bias = ptr(layer.bias)
     d.residual = ptr(residual, torch.float32) if residual is not None else None
     d.res_cstride = residual.shape[-1] if residual is not None else 0
@@ -85,9 +111,9 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     if PROFILE is not None and impl == 'mfma':
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        call('l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma', d, stream())
+        call('l3c_conv_wino4' if wino4 else 'l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma', d, stream())
         e1.record()
-        key = ('conv_wino_kernel' if wino else 'conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
+        key = ('conv_wino4_kernel' if wino4 else 'conv_wino_kernel' if wino else 'conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
                'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
         if PROFILE_DETAIL:
             key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '',
@@ -95,7 +121,8 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         nbytes = 4.0 * B * (H * W * layer.Cin + Ho * Wo * layer.Cout * (2 if residual is not None else 1))   # in + out (+ residual), once
         PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1))
         return out
-    call('l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct', d, stream())
+    call('l3c_conv_wino4' if wino4 else 'l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct',
+         d, stream())
     return out
 
 

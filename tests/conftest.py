@@ -30,23 +30,29 @@ def golden():
     return load
 
 
+_CKPT_CACHE = {}
+
+
+def _l3c_checkpoint(calibrated):
+    if calibrated not in _CKPT_CACHE:
+        import l3c_pytorch_amd  # noqa: F401
+        from l3c_pytorch_amd.helpers import config_parser, synthetic
+        cfg = config_parser.parse_builtin('ms', 'cr')
+        _CKPT_CACHE[calibrated] = (cfg, synthetic.make_state_dict(cfg, 0, calibrated=calibrated))
+    return _CKPT_CACHE[calibrated]
+
+
 @pytest.fixture(scope='session')
 def synthetic_l3c():
     """(config_ms, state_dict) of the seeded synthetic L3C checkpoint used by tests/golden/make_golden.py."""
-    import l3c_pytorch_amd  # noqa: F401
-    from l3c_pytorch_amd.helpers import config_parser, synthetic
-    cfg = config_parser.parse_builtin('ms', 'cr')
-    return cfg, synthetic.make_state_dict(cfg, 0)
+    return _l3c_checkpoint(False)
 
 
 @pytest.fixture(scope='session')
 def synthetic_l3c_cal():
     """(config_ms, state_dict) of the CALIBRATED synthetic checkpoint (tests/golden/make_calibrated.py): mixtures that cover the
     data, every bottleneck level in use."""
-    import l3c_pytorch_amd  # noqa: F401
-    from l3c_pytorch_amd.helpers import config_parser, synthetic
-    cfg = config_parser.parse_builtin('ms', 'cr')
-    return cfg, synthetic.make_state_dict(cfg, 0, calibrated=True)
+    return _l3c_checkpoint(True)
 
 
 # (fixture file, uses the calibrated checkpoint): every reference-generated L3C network fixture
@@ -54,7 +60,5 @@ NET_FIXTURES = [('net_32.npz', False), ('net_cal_32.npz', True), ('net_cal_64x96
 
 
 @pytest.fixture(scope='session')
-def l3c_checkpoint(synthetic_l3c, synthetic_l3c_cal):
-    def get(calibrated):
-        return synthetic_l3c_cal if calibrated else synthetic_l3c
-    return get
+def l3c_checkpoint():
+    return _l3c_checkpoint

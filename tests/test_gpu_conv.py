@@ -45,21 +45,23 @@ def test_conv_mfma_vs_torch(KS, stride, dil, Cin, Cout, B, H, W):
     b = torch.randn(Cout, generator=g)
     ref = _ref_conv(x, w, b, stride, dil)
     layer = ops.PackedConv(w, b, stride=stride, dilation=dil)
-    got = ops.conv(_nhwc(x).cuda(), layer, impl='mfma').cpu().permute(0, 3, 1, 2)
+    IMPL = 'gemm' if KS == 3 else 'mfma'     # 3x3: the implicit-GEMM kernel (the product dispatches 3x3 layers to Winograd)
+    got = ops.conv(_nhwc(x).cuda(), layer, impl=IMPL).cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item()
     assert err < 3e-5, err
     direct = ops.conv(_nhwc(x).cuda(), layer, impl='direct').cpu().permute(0, 3, 1, 2)
     assert (direct - ref).abs().max().item() < 3e-5
     # determinism: same launch twice is bit-identical; a batch of two equals two single launches
-    again = ops.conv(_nhwc(x).cuda(), layer, impl='mfma').cpu().permute(0, 3, 1, 2)
+    again = ops.conv(_nhwc(x).cuda(), layer, impl=IMPL).cpu().permute(0, 3, 1, 2)
     assert torch.equal(got, again)
     if B > 1:
-        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, impl='mfma').cpu().permute(0, 3, 1, 2)
+        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, impl=IMPL).cpu().permute(0, 3, 1, 2)
         assert torch.equal(single, got[1:2])
 
 
 def test_conv_epilogues():
+    """the product's dispatch (3x3 stride 1 -> Winograd F(4x4,3x3): within 1e-4 of torch's fp32 conv for unit-scale data)."""
     from l3c_pytorch_amd import ops
     g = torch.Generator().manual_seed(1)
     B, H, W = 2, 12, 40
@@ -71,20 +73,20 @@ def test_conv_epilogues():
     xd, rd = _nhwc(x).cuda(), _nhwc(res).cuda()
     ref = _ref_conv(x, w, b, 1, 1)
     got = ops.conv(xd, layer, relu=True).cpu().permute(0, 3, 1, 2)
-    assert (got - F.relu(ref)).abs().max() < 3e-5
+    assert (got - F.relu(ref)).abs().max() < 1e-4
     got = ops.conv(xd, layer, residual=rd).cpu().permute(0, 3, 1, 2)
-    assert (got - (ref + res)).abs().max() < 3e-5
+    assert (got - (ref + res)).abs().max() < 1e-4
     # channel-slice output (the atrous branches write into the 192-wide concat buffer)
     cat = torch.zeros(B, H, W, 192, device='cuda')
     ops.conv(xd, layer, out=cat, out_coff=64)
-    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2) - ref).abs().max() < 3e-5
+    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2) - ref).abs().max() < 1e-4
     assert float(cat[..., :64].abs().max()) == 0 and float(cat[..., 128:].abs().max()) == 0
     # pixel shuffle epilogue == nn.PixelShuffle(2) of the 256-channel conv (edsr.py:98-99)
     w4 = torch.randn(256, 64, 3, 3, generator=g) / 24
     b4 = torch.randn(256, generator=g)
     up = ops.conv(xd, ops.PackedConv(w4, b4), pixel_shuffle=True).cpu().permute(0, 3, 1, 2)
     ref_up = F.pixel_shuffle(_ref_conv(x, w4, b4, 1, 1), 2)
-    assert up.shape == ref_up.shape and (up - ref_up).abs().max() < 3e-5
+    assert up.shape == ref_up.shape and (up - ref_up).abs().max() < 1e-4
 
 
 def test_rgb_head_vs_torch(synthetic_l3c):
@@ -180,21 +182,18 @@ def test_winograd_conv_vs_implicit_gemm_and_fp64(dil, Cin, Cout, B, H, W, relu, 
     layer = ops.PackedConv(w, b, dilation=dil)
     assert layer.packed_wino is not None
     kw = dict(relu=relu, residual=_nhwc(r).cuda() if res else None, pixel_shuffle=shuffle)
-    got = ops.conv(_nhwc(x).cuda(), layer, **kw).cpu().permute(0, 3, 1, 2)          # dispatches to l3c_conv_wino
+    got = ops.conv(_nhwc(x).cuda(), layer, impl='wino2', **kw).cpu().permute(0, 3, 1, 2)          # l3c_conv_wino
     assert got.shape == ref.shape
     assert (got.double() - ref).abs().max().item() < 3e-5
     if Cin % 16 == 0:
-        wino = layer.packed_wino
-        layer.packed_wino = None                                                       # same layer through l3c_conv_mfma
-        gemm = ops.conv(_nhwc(x).cuda(), layer, **kw).cpu().permute(0, 3, 1, 2)
-        layer.packed_wino = wino
+        gemm = ops.conv(_nhwc(x).cuda(), layer, impl='gemm', **kw).cpu().permute(0, 3, 1, 2)   # same layer through l3c_conv_mfma
         assert (gemm.double() - ref).abs().max().item() < 3e-5
         assert (got - gemm).abs().max().item() < 3e-5
-    again = ops.conv(_nhwc(x).cuda(), layer, **kw).cpu().permute(0, 3, 1, 2)
+    again = ops.conv(_nhwc(x).cuda(), layer, impl='wino2', **kw).cpu().permute(0, 3, 1, 2)
     assert torch.equal(got, again)
     if B > 1:
         kw1 = dict(kw, residual=_nhwc(r[1:2]).cuda() if res else None)
-        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, **kw1).cpu().permute(0, 3, 1, 2)
+        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, impl='wino2', **kw1).cpu().permute(0, 3, 1, 2)
         assert torch.equal(single, got[1:2])
 
 
@@ -242,7 +241,7 @@ def test_winograd_tiles_per_block_is_only_a_schedule(wino_tpb, dil, Cout, B, H, 
         wino_tpb(n)
         # poison the output first: every element must be written
         out = torch.full((B, 2 * H, 2 * W, Cout // 4) if shuffle else (B, H, W, Cout), float('nan'), device='cuda')
-        outs.append(ops.conv(xd, layer, out=out, **kw).cpu())
+        outs.append(ops.conv(xd, layer, out=out, impl='wino2', **kw).cpu())
     assert (outs[0].permute(0, 3, 1, 2).double() - ref).abs().max().item() < 3e-5
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
@@ -263,13 +262,13 @@ def test_winograd_at_the_headline_layer_sizes(wino_tpb, dil, Cout, B, H, W, shuf
     layer = ops.PackedConv(w, b, dilation=dil)
     kw = dict(residual=_nhwc(r).cuda() if r is not None else None, pixel_shuffle=shuffle)
     xd = _nhwc(x).cuda()
-    got = ops.conv(xd, layer, **kw)
-    wino, layer.packed_wino = layer.packed_wino, None
-    gemm = ops.conv(xd, layer, **kw)
-    layer.packed_wino = wino
+    got = ops.conv(xd, layer, impl='wino2', **kw)
+    gemm = ops.conv(xd, layer, impl='gemm', **kw)
     assert (got - gemm).abs().max().item() < 3e-5
+    f4 = ops.conv(xd, layer, impl='wino4', **kw)                  # the F(4x4,3x3) kernel at the same sizes
+    assert (f4 - gemm).abs().max().item() < 1e-4
     wino_tpb(1)
-    assert torch.equal(ops.conv(xd, layer, **kw), got)
+    assert torch.equal(ops.conv(xd, layer, impl='wino2', **kw), got)
     # fp64 on a window that contains the image's bottom-right corner
     hs, ws = H - 40, W - 70
     pad = 2 * dil
@@ -322,7 +321,7 @@ def test_winograd_random_shapes_vs_implicit_gemm(wino_tpb):
     """40 seeded random layer shapes (sizes 1..150 x 1..300, every dilation, every epilogue, random tiles-per-block setting, output
     written into a channel slice of a wider NaN-poisoned tensor) through the Winograd kernel and the implicit-GEMM kernel: equal
     within 3e-5, nothing written outside the slice."""
-    from l3c_pytorch_amd import ops
+    from l3c_pytorch_amd import _lib, ops
     rng = np.random.RandomState(1234)
     g = torch.Generator().manual_seed(99)
     for case in range(40):
@@ -342,14 +341,21 @@ def test_winograd_random_shapes_vs_implicit_gemm(wino_tpb):
         co = Cout // 4 if mode == 3 else Cout
         Ho, Wo = (2 * H, 2 * W) if mode == 3 else (H, W)
         out = torch.full((B, Ho, Wo, co + 8), float('nan'), device='cuda')
-        ops.conv(x, layer, out=out, out_coff=4, **kw)
-        wino, layer.packed_wino = layer.packed_wino, None
-        ref = ops.conv(x, layer, **kw)
-        layer.packed_wino = wino
+        ops.conv(x, layer, out=out, out_coff=4, impl='wino2', **kw)
+        ref = ops.conv(x, layer, impl='gemm', **kw)
         got = out[..., 4:4 + co]
         assert not bool(torch.isnan(got).any()), (case, dil, H, W, B, mode, Cout, Cin)
         assert (got - ref).abs().max().item() < 3e-5, (case, dil, H, W, B, mode, Cout, Cin)
         assert bool(torch.isnan(out[..., :4]).all()) and bool(torch.isnan(out[..., 4 + co:]).all()), case
+        # the same layer through the F(4x4,3x3) kernel (random tiles-per-block setting too)
+        _lib.load().l3c_conv_wino4_set_tiles_per_block(int(rng.choice([0, 1, 2, 4, 6])))
+        out4 = torch.full((B, Ho, Wo, co + 8), float('nan'), device='cuda')
+        ops.conv(x, layer, out=out4, out_coff=4, impl='wino4', **kw)
+        got4 = out4[..., 4:4 + co]
+        assert not bool(torch.isnan(got4).any()), ('f4', case, dil, H, W, B, mode, Cout, Cin)
+        assert (got4 - ref).abs().max().item() < 1e-4, ('f4', case, dil, H, W, B, mode, Cout, Cin)
+        assert bool(torch.isnan(out4[..., :4]).all()) and bool(torch.isnan(out4[..., 4 + co:]).all()), ('f4', case)
+    _lib.load().l3c_conv_wino4_set_tiles_per_block(0)
 
 
 def test_pointwise_random_shapes_vs_implicit_gemm():
@@ -376,3 +382,81 @@ def test_pointwise_random_shapes_vs_implicit_gemm():
         assert not bool(torch.isnan(got).any()), (case, Cin, Cout, B, H, W)
         assert (got - ref).abs().max().item() < 3e-5, (case, Cin, Cout, B, H, W)
         assert bool(torch.isnan(out[..., :2]).all()) and bool(torch.isnan(out[..., 2 + Cout:]).all()), case
+
+
+# ---- Winograd F(4x4,3x3) (csrc/conv_wino4.hip) ------------------------------------------------------------------------------------
+
+WINO4_CASES = WINO_CASES + [
+    (1, 64, 64, 1, 16, 16, False, False, False),       # exactly one block tile
+    (1, 64, 64, 1, 16, 96, False, True, False),        # one row of 6 tiles: the block walks them over one pipeline
+    (1, 64, 64, 2, 37, 131, True, True, False),        # ragged in both directions, several groups per row
+    (2, 64, 64, 1, 40, 72, False, False, False),
+    (4, 64, 64, 2, 70, 90, False, True, False),
+    (1, 32, 48, 1, 20, 20, False, False, False),       # 4 chunks, Cout < 64 and not a multiple of 16... 48 = 3 waves' worth
+]
+
+
+@pytest.mark.parametrize('dil,Cin,Cout,B,H,W,relu,res,shuffle', WINO4_CASES)
+def test_winograd_f4_conv_vs_fp64_and_f2(dil, Cin, Cout, B, H, W, relu, res, shuffle):
+    """Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 against an fp64 reference and the F(2x2,3x3) kernel.  The transform constants
+    (up to 8 in A^T, 5 in B^T) cost accuracy: unit-scale data stay within 1e-4 of fp64 here (measured ~2e-5; F(2x2): 3e-6);
+    what the L3C forward keeps of north_star's 1e-5 is measured at full size in tests/test_gpu_headline.py.  Determinism and
+    batch invariance are exact."""
+    from l3c_pytorch_amd import ops
+    if shuffle and (relu or res):
+        pytest.skip('no such layer')
+    g = torch.Generator().manual_seed(dil * 1000 + H * 10 + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / np.sqrt(Cin * 9)
+    b = torch.randn(Cout, generator=g)
+    r = torch.randn(B, Cout, H, W, generator=g) if res else None
+    ref = F.conv2d(x.double(), w.double(), b.double(), dilation=dil, padding=dil)
+    if relu:
+        ref = ref.clamp(min=0)
+    if res:
+        ref = ref + r.double()
+    if shuffle:
+        ref = F.pixel_shuffle(ref, 2)
+    layer = ops.PackedConv(w, b, dilation=dil)
+    assert layer.packed_wino4 is not None
+    kw = dict(relu=relu, residual=_nhwc(r).cuda() if res else None, pixel_shuffle=shuffle)
+    got = ops.conv(_nhwc(x).cuda(), layer, impl='wino4', **kw).cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    print('F(4x4,3x3) max |err| vs fp64: {:.3g}'.format(err))
+    assert err < 1e-4, err
+    again = ops.conv(_nhwc(x).cuda(), layer, impl='wino4', **kw).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, again)
+    if B > 1:
+        kw1 = dict(kw, residual=_nhwc(r[1:2]).cuda() if res else None)
+        single = ops.conv(_nhwc(x[1:2]).cuda(), layer, impl='wino4', **kw1).cpu().permute(0, 3, 1, 2)
+        assert torch.equal(single, got[1:2])
+
+
+def test_winograd_f4_channel_slices_and_tiles_per_block():
+    """output into a channel slice of a wider tensor (the atrous branches write into the 192-wide concat), and the result does not
+    depend on how many tiles a block walks."""
+    from l3c_pytorch_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 33, 100
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    layer = ops.PackedConv(w, b)
+    xd = _nhwc(x).cuda()
+    cat = torch.zeros(B, H, W, 192, device='cuda')
+    ops.conv(xd, layer, out=cat, out_coff=64, impl='wino4')
+    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2).double() - ref).abs().max() < 1e-4
+    assert float(cat[..., :64].abs().max()) == 0 and float(cat[..., 128:].abs().max()) == 0
+    lib = _lib.load()
+    outs = []
+    prev = lib.l3c_conv_wino4_set_tiles_per_block(0)
+    try:
+        for n in (0, 1, 2, 3, 7):
+            lib.l3c_conv_wino4_set_tiles_per_block(n)
+            outs.append(ops.conv(xd, layer, impl='wino4'))
+    finally:
+        lib.l3c_conv_wino4_set_tiles_per_block(prev)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])

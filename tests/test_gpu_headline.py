@@ -99,10 +99,11 @@ def _group_errs(P, ref, num_params):
     return out
 
 
-# tolerances, RELATIVE to the largest magnitude of the tensor / parameter group: the measured errors on
-# this image (profiles/r03_parity_768x512_*.json) x ~2.5 -- all inside north_star's 1e-5.  The two sides sum ~40 layers of
-# 576-term dot products in different orders (Winograd on MFMA k-blocks vs the CPU's direct convolution).
-TOL_REL = 5e-6
+# tolerance, RELATIVE to the largest magnitude of the tensor / parameter group: north_star's 1e-5.  Measured
+# on this image (profiles/r03_parity_768x512_*.json) with the Winograd F(4x4,3x3) convolutions: P within 3.5e-6, decoder features
+# within 6.6e-6 (F(2x2,3x3), round 2: 1.1e-6 / 1.9e-6).  The two sides sum ~40 layers of 576-term dot products in different
+# orders and through different transforms (Winograd on MFMA k-blocks vs the CPU's direct convolution).
+TOL_REL = 1e-5
 
 
 def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c, calibrated):

@@ -1,0 +1,32 @@
+#!/usr/bin/env python
+"""Development: time the F(4x4,3x3) kernel variants with parts removed (csrc/build.py --variant w4pN "-DL3C_W4_PROBE=N", loaded through
+L3C_LIB).  Wrong results by construction; only the time means something."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import l3c_pytorch_amd  # noqa: E402,F401
+from l3c_pytorch_amd import ops  # noqa: E402
+
+g = torch.Generator().manual_seed(0)
+B, H, W = 32, 256, 384
+w = torch.randn(64, 64, 3, 3, generator=g) / 24
+b = torch.randn(64, generator=g)
+layer = ops.PackedConv(w, b)
+x = torch.randn(B, H, W, 64, generator=g).cuda()
+r = torch.randn(B, H, W, 64, generator=g).cuda()
+out = []
+for name, kw in [('relu', dict(relu=True)), ('res', dict(residual=r))]:
+    fn = lambda: ops.conv(x, layer, impl='wino4', **kw)   # noqa: E731
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    out.append('{} {:.3f} ms'.format(name, e0.elapsed_time(e1) / 10))
+print(os.environ.get('L3C_LIB', 'product').split('_')[-1], ' | '.join(out))
