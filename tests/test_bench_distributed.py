@@ -45,3 +45,25 @@ def test_bench_world_size_2_under_torch_distributed_run():
 def test_bench_world_size_1_under_torch_distributed_run():
     r = _run(1, steps=2)
     assert r['n_gpus'] == 1 and r['ms_per_step'] >= 10.0
+
+
+def test_plain_bench_gpus_2_spawns_its_own_ranks():
+    """The driver's command shape WITHOUT a launcher: `python bench.py --gpus 2` must start two ranks itself and report n_gpus = 2
+    (round-2 verdict: it used to run one rank and say n_gpus = 1)."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--stub-step']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '1'
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['steps'] == 3 and r['ms_per_step'] >= 20.0
+
+
+def test_gpus_flag_must_match_the_launcher():
+    """--gpus 2 under a 1-rank launcher is an error, not a silently mislabelled line."""
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--stub-step']
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and not [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
