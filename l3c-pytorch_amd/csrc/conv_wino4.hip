@@ -146,19 +146,28 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const int tx_first = (int)(grp - t_y * (unsigned)p.groups_x) * p.tpb;  // first tile of this block
     const int n_t = min(p.tpb, p.tiles_x - tx_first);
 
-    // ---- patch fetch: piece i = tid + 256 it -> pixel i / 2 of the 18 x 18 patch, channels 4 (i & 1) .. + 3 of the chunk
-    int patch_off[NIT];
+    // ---- patch fetch: thread (r0 = tid / 36 < 6, column c = tid % 36 / 2, half = tid & 1) fetches the 16-byte pieces (channels
+    // 4 half .. + 3 of the chunk) of the patch pixels (r0 + 6 k, c), k = 0..2: ONE per-lane byte offset, the rows 6 apart by a
+    // uniform offset.  Zero padding = the descriptor's range check: a row below the image lies beyond the buffer, a row above it at
+    // a negative (= huge unsigned) offset, and a thread whose column is outside the image starts from an offset that keeps all
+    // three of its pieces out of range.  216 threads fetch, the other 40 idle (offsets out of range, nothing stored).
+    const int pf_r0 = tid / (2 * PW), pf_j = tid - pf_r0 * (2 * PW);
+    const bool pf_thread = pf_r0 < 6;
+    const int pf_row_b = 6 * dil * p.W * p.in_cstride * 4;                     // six patch rows on, in bytes
+    const int pf_lds = (pf_r0 * PW + (pf_j >> 1)) * PSR + (pf_j & 1) * 4;       // LDS position of piece 0 (floats); + k * 6 * PW * PSR
+    int patch_off;
+    auto fresh_tid = [&]() {   // the thread index, recomputed where it is used rarely (kept out of the registers the MFMA loop holds)
+        unsigned m = ~0u;
+        asm volatile("" : "+s"(m));
+        return wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
+    };
     auto set_patch_tile = [&](int t) {
-        const int x0 = px + dil * ((tx_first + t) * OT - 1);
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 256;
-            const int c4 = i & 1, pix = i >> 1;
-            const int r = pix / PW, ci = pix - r * PW;
-            const int iy = py + dil * (sy0 - 1 + r), ix = x0 + dil * ci;
-            const bool ok = i < N_PIECES && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            patch_off[it] = ok ? ((iy * p.W + ix) * p.in_cstride + c4 * 4) * 4 : OOB;
-        }
+        const int tf = fresh_tid();
+        const int r0 = tf / (2 * PW), j = tf - r0 * (2 * PW);
+        const int iy = py + dil * (sy0 - 1 + r0), ix = px + dil * ((tx_first + t) * OT - 1 + (j >> 1));
+        const bool ok = r0 < 6 && ix >= 0 && ix < p.W;
+        // (iy may be negative: the offset wraps to a huge unsigned value and the load returns zero; iy + 6 k then comes back in range)
+        patch_off = ok ? ((iy * p.W + ix) * p.in_cstride + (j & 1) * 4) * 4 : (int)0xC0000000;   // (+ 2 rows: still beyond 2 GB)
     };
     int pf_tile = 0, pf_cc = 0;   // the prefetch pointer: (tile, chunk) of the next patch to fetch
     auto pf_advance = [&]() {
@@ -176,11 +185,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     f32x4 stage[NIT];
     auto fetch_piece = [&](int it) {
         if constexpr (L3C_W4_PROBE & 1) return;
-        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], pf_cc * CK * 4, 0));
+        stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off + it * pf_row_b, pf_cc * CK * 4, 0));
     };
     auto store_piece = [&](float *dst, int it, const f32x4 &v) {
-        const int i = tid + it * 256;
-        if (it < NIT - 1 || i < N_PIECES) *reinterpret_cast<f32x4 *>(&dst[(i >> 1) * PSR + (i & 1) * 4]) = v;
+        if (pf_thread) *reinterpret_cast<f32x4 *>(&dst[pf_lds + it * (6 * PW * PSR)]) = v;
     };
 
     // ---- B operands: uniform descriptor + fixed per-lane byte offset + scalar offset; all loads unconditional
@@ -219,13 +227,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     auto body = [&](auto th_c) __attribute__((always_inline)) {
         constexpr int TH = decltype(th_c)::value;
         float T[3][6];    // rows xi = 3 TH .. 3 TH + 2 of B^T d for this thread's (tile, channel)
-        float L[5];       // raw rows TH .. TH + 4 of one patch column
+        float L[2][5];    // raw rows TH .. TH + 4 of one patch column (two columns in flight)
         auto tr_load = [&](const float *src, int col) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) L[i] = src[(i * PW + col) * PSR];
+            for (int i = 0; i < 5; ++i) L[col & 1][i] = src[(i * PW + col) * PSR];
         };
         auto tr_col = [&](int col) {
-            const float(&l)[5] = L;
+            const float(&l)[5] = L[col & 1];
             const float x = __builtin_fmaf(4.0f, l[0], __builtin_fmaf(-5.0f, l[2], l[4]));
             if constexpr (TH == 0) {   // xi = 0, 1, 2 from raw rows 0 .. 4
                 const float a = __builtin_fmaf(-4.0f, l[2], l[4]), bb = __builtin_fmaf(-4.0f, l[1], l[3]);
@@ -257,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             for (int k = 0; k < 2; ++k) {
 #pragma unroll
                 for (int it = 0; it < NIT; ++it)
-                    first[k][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off[it], pf_cc * CK * 4, 0));
+                    first[k][it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off + it * pf_row_b, pf_cc * CK * 4, 0));
                 pf_advance();
             }
 #pragma unroll
@@ -287,10 +295,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): nothing of the prologue stays in flight (see conv_wino.hip)
 
         // Chunk g (buffer parity par = g & 1) -- invariants at its start: V[par] complete and visible; raw[par ^ 1] = patch of
-        // chunk g + 1, visible; `stage` = patch of chunk g + 2 (in flight); b_ring = B of pairs 0..3 (in flight); a_ring = A of
-        // pairs 0, 1; the prefetch pointer is at chunk g + 3.
-        auto chunk = [&](const int cc, auto first_c, auto par_c) __attribute__((always_inline)) {
-            constexpr bool FIRST = decltype(first_c)::value;
+        // chunk g + 1, visible; `stage` = patch of chunk g + 2 (in flight); a_ring = A of pairs 0, 1; the prefetch pointer is at chunk
+        // g + 3; B operands: b_ring (slot (pair + 2 par) & 3) holds pairs 0..2 (FIRST chunk of a tile: 0..3), b_burst pairs 3..9.
+        //
+        // vmcnt is IN ORDER: a B load issued behind a patch fetch cannot be consumed before the patch has arrived (HBM latency for
+        // one chunk in four -- a pixel's 32 channels share a 128-byte line -- and L2 latency otherwise), and with four pairs of
+        // lookahead that stalled the wave in every chunk [probe: no patch fetch -15 %].  So the B operands of pairs 3..9 of the NEXT
+        // chunk are fetched in one burst (seven register quads: the registers the input transform has just released -- it runs in
+        // pairs 10..15, the burst is consumed by pair 9) IMMEDIATELY BEFORE the patch fetch at pair 16: the first B load issued behind
+        // the patch is the one of pair 10 at pair 6 of the next chunk, needed at pair 10 -- the patch has 12 pairs' time to arrive.
+        // KIND 0: first chunk of a tile (all its B operands come through the ring: the chunk before it was the last of the previous
+        // tile or the prologue), 1: middle, 2: last chunk of a tile (no burst: the output transform needs the registers).
+        f32x4 b_burst[7];
+        auto chunk = [&](const int cc, auto kind_c, auto par_c) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_c)::value;
+            constexpr bool FIRST = KIND == 0, LAST = KIND == 2;
             constexpr int par = decltype(par_c)::value;
             const int cc_b = cc + 1 == n_cc ? 0 : cc + 1;   // the next chunk's weights (the next tile starts over with chunk 0)
             const float *a_cur = lds + (par ? V_OFF1 : V_OFF0) + a_lane;
@@ -299,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             const float *r_src = lds + (par ? RAW_OFF0 : RAW_OFF1) + t_src;   // raw[par ^ 1]
             float *r_dst = lds + (par ? RAW_OFF1 : RAW_OFF0);                 // raw[par]
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            constexpr bool TR = !(L3C_W4_PROBE & 2), ST = !(L3C_W4_PROBE & 32), LB = !(L3C_W4_PROBE & 4);
 #define L3C_W4_MFMA(Q, A, B, ZERO)                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (FIRST && (ZERO) && (Q) != 7) ? zero4 : acc[Q], 0, 0, 0); \
@@ -306,31 +326,48 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
             for (int pp = 0; pp < NPP; ++pp) {
                 const f32x4 &A = a_ring[pp & 1];
-                const f32x4 &Bv = b_ring[(pp + 2 * par) & 3];   // 18 pairs per chunk: the ring position shifts by 2 per chunk
+                const bool from_burst = !FIRST && pp >= 3 && pp <= 9;
+                const f32x4 &Bv = from_burst ? b_burst[pp >= 3 && pp <= 9 ? pp - 3 : 0] : b_ring[(pp + 2 * par) & 3];
                 if (pp == NPP - 1) {
                     // everything chunk g + 1 needs from this wave is issued: V[par ^ 1] written, patch g + 2 stored
                     if constexpr (!(L3C_W4_PROBE & 8)) __syncthreads();
                     a_ring[0] = *reinterpret_cast<const f32x4 *>(a_nxt);
                 }
                 L3C_W4_MFMA(2 * pp, A[0], Bv[0], true)
-                constexpr bool TR = !(L3C_W4_PROBE & 2), ST = !(L3C_W4_PROBE & 32);
-                if (TR && pp < 6) tr_load(r_src, pp);
-                if (TR && (pp == 7 || pp == 9 || pp == 11)) tr_row((pp - 7) >> 1);
-                if (ST && pp == 13) store_piece(r_dst, 0, stage[0]);
-                if (pp == 14) fetch_piece(0);
+                if (TR && pp >= 10 && pp <= 12) tr_load(r_src, 2 * (pp - 10));
+                if (TR && pp >= 13 && pp <= 15) tr_row(pp - 13);
+                if (ST && pp == 16) store_piece(r_dst, 0, stage[0]);
+                if (ST && pp == 16) store_piece(r_dst, 1, stage[1]);
                 L3C_W4_MFMA(2 * pp + 1, A[2], Bv[2], true)
-                if (TR && (pp == 8 || pp == 10 || pp == 12)) tr_write(v_next, (pp - 8) >> 1);
-                if (ST && pp == 13) store_piece(r_dst, 1, stage[1]);
-                if (pp == 14) fetch_piece(1);
+                if (TR && pp >= 10 && pp <= 12) tr_load(r_src, 2 * (pp - 10) + 1);
+                if (ST && pp == 16) store_piece(r_dst, 2, stage[2]);
+                if (LB && !LAST && pp == 15) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) b_burst[k] = fetch_b(cc_b, 3 + k);
+                }
                 L3C_W4_MFMA(2 * pp, A[1], Bv[1], false)
-                if (TR && pp < 6) tr_col(pp);
-                if (ST && pp == 13) store_piece(r_dst, 2, stage[2]);
-                if (pp == 14) fetch_piece(2);
-                if (pp == 15) pf_advance();
+                if (TR && pp >= 10 && pp <= 12) tr_col(2 * (pp - 10));
+                if (TR && pp >= 13 && pp <= 15) tr_write(v_next, pp - 13);
                 L3C_W4_MFMA(2 * pp + 1, A[3], Bv[3], false)
+                // (the rings are reloaded behind the pair's last MFMA: A and Bv are references into them)
                 if (pp < NPP - 2) a_ring[pp & 1] = *reinterpret_cast<const f32x4 *>(a_cur + (pp + 2) * VPP);
                 if (pp == NPP - 1) a_ring[1] = *reinterpret_cast<const f32x4 *>(a_nxt + VPP);
-                if constexpr (!(L3C_W4_PROBE & 4)) b_ring[(pp + 2 * par) & 3] = pp + 4 < NPP ? fetch_b(cc, pp + 4) : fetch_b(cc_b, pp + 4 - NPP);
+                if (TR && pp >= 10 && pp <= 12) tr_col(2 * (pp - 10) + 1);
+                // the ring: pair pp + 4 -- of this chunk, or (numbered on) of the next one, whose pairs 3..9 come from the burst
+                if constexpr (LB) {
+                    const int nxt = pp + 4;
+                    const bool ring_load = nxt < NPP ? (FIRST || nxt >= 10) : (LAST || nxt - NPP <= 2);
+                    if (ring_load) b_ring[(nxt + 2 * par) & 3] = nxt < NPP ? fetch_b(cc, nxt) : fetch_b(cc_b, nxt - NPP);
+                }
+                if (pp == 16) {
+                    if (LB && !LAST) {
+#pragma unroll
+                        for (int k = 3; k < 7; ++k) b_burst[k] = fetch_b(cc_b, 3 + k);
+                    }
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) fetch_piece(it);   // patch of chunk g + 3, behind the burst
+                    pf_advance();
+                }
             }
 #undef L3C_W4_MFMA
         };
@@ -342,20 +379,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "v"(bias_init));
                 acc[7][r] = v;
             }
-            chunk(0, std::true_type{}, std::integral_constant<int, 0>{});
-            chunk(1, std::false_type{}, std::integral_constant<int, 1>{});
-            for (int cc = 2; cc < n_cc; cc += 2) {
-                chunk(cc, std::false_type{}, std::integral_constant<int, 0>{});
-                chunk(cc + 1, std::false_type{}, std::integral_constant<int, 1>{});
+            chunk(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            for (int cc = 1; cc + 1 < n_cc; cc += 2) {
+                chunk(cc, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                chunk(cc + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
             }
+            chunk(n_cc - 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
 
             // ---- output transform Y = A^T M A, in registers: lane (q = lane >> 4, n = lane & 15) holds, in register r of the 36
             // fragments, the transformed tile (ty, tx) = (q, r) of output channel n.  The results leave through a small
             // wavefront-private LDS window that turns "one channel, 16 pixels per lane" into "four adjacent channels of one pixel
             // per lane": round (r, i) = output row i of the four tiles (., r) -> 16 pixels x 16 channels: four ds_write_b32, one
             // ds_read_b128, one 16-byte store (and residual load) per lane -- 16 of each per tile instead of 64 four-byte ones.
-            const int q = lane >> 4, n = lane & 15;
-            const int q2 = lane >> 4, j2 = (lane >> 2) & 3, c4 = lane & 3;   // store layout: pixel (4 q2 + i, 4 r + j2), channels 4 c4 ..
+            // Everything the epilogue derives from the lane index is recomputed per tile (the opaque mask hides the index from the
+            // loop-invariant code motion): held across the chunk loop these values would push the accumulators out of the registers.
+            const int ln = fresh_tid() & 63;
+            const int q = ln >> 4, n = ln & 15;
+            const int q2 = ln >> 4, j2 = (ln >> 2) & 3, c4 = ln & 3;   // store layout: pixel (4 q2 + i, 4 r + j2), channels 4 c4 ..
             const int sx0 = (tx_first + t) * OT;
             const bool lane_ok = chunk_o * 64 + wave * 16 + (SHUFFLE ? 0 : c4 * 4) < p.Cout;   // Cout % 4 (shuffle: % 16) == 0
             int o_lane, r_lane = 0;

@@ -36,7 +36,7 @@ b = torch.randn(64, generator=g)
 layer = ops.PackedConv(w, b)
 x = torch.randn(2, 50, 70, 64, generator=g).cuda()
 ref64 = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double(), b.double(), padding=1).permute(0, 2, 3, 1)
-for impl in ('mfma', 'wino4'):
+for impl in ('wino2', 'wino4'):
     got = ops.conv(x, layer, impl=impl)
     print(impl, 'max |err| vs fp64: %.3g' % (got.double().cpu() - ref64).abs().max().item())
 
@@ -57,12 +57,14 @@ for (H, W, cout, dil, relu, res, shuffle, label) in [
     r = torch.randn(B, H, W, cout, generator=g).cuda() if res else None
     flops = 2.0 * B * H * W * cout * 64 * 9
     line = '{:34s} B{:3d}'.format(label, B)
-    outs = {}
-    for impl in ('mfma', 'wino4'):
-        fn = lambda: ops.conv(x, layer, relu=relu, residual=r, pixel_shuffle=shuffle, impl=impl)   # noqa: E731
-        ms = timed(fn, a.iters)
-        outs[impl] = fn()
-        line += ' | {} {:7.3f} ms {:6.1f} alg. TFLOP/s'.format('F(2x2)' if impl == 'mfma' else 'F(4x4)', ms, flops / ms / 1e9)
-    line += ' | max diff %.2e' % (outs['mfma'] - outs['wino4']).abs().max().item()
+    outs, best = {}, {}
+    for rep in range(2):          # alternate, keep the better of two: the clock the chip grants drifts by several per cent
+        for impl in ('wino2', 'wino4'):
+            fn = lambda: ops.conv(x, layer, relu=relu, residual=r, pixel_shuffle=shuffle, impl=impl)   # noqa: E731
+            best[impl] = min(best.get(impl, 1e9), timed(fn, a.iters))
+            outs[impl] = fn()
+    for impl in ('wino2', 'wino4'):
+        line += ' | {} {:7.3f} ms {:6.1f} alg. TFLOP/s'.format('F(2x2)' if impl == 'wino2' else 'F(4x4)', best[impl], flops / best[impl] / 1e9)
+    line += ' | max diff %.2e' % (outs['wino2'] - outs['wino4']).abs().max().item()
     print(line)
     sys.stdout.flush()
