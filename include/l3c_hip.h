@@ -298,6 +298,8 @@ int l3c_to_q_quantize(const float *feat, const float *w, const float *b, const f
 /*
  * Decoder input: 1x1 conv C -> Cf on the quantised bottleneck (+ the coarser decoder's features), net.py:178-180.
  *   bn_q planar [B][C][HW]; w [Cf][C], b [Cf]; fuse pixel-major [B][HW][Cf] or NULL; out pixel-major [B][HW][Cf]
+ *   Limits: C <= 8 (the bottleneck's weights live in registers; q.C is 5 or 3 in every shipped config), Cf % 4 == 0 and
+ *   256 % (Cf / 4) == 0, HW < 2^31.  Anything else returns L3C_ERR_INVALID_ARG.
  */
 int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float *fuse, int64_t B, int64_t HW, int C,
                  int Cf, float *out, l3c_stream_t stream);

@@ -205,6 +205,10 @@ class Bitcoding(object):
         self.auto_recurse = int(auto_recurse)
         if self.auto_recurse and not blueprint.net.config_ms.rgb_bicubic_baseline:
             raise ValueError('auto_recurse is only defined for the RGB baselines')
+        if self.auto_recurse and blueprint.net.scales != 1:
+            # the decoder accepts extra scale records only for the single-scale RGB Shared model (decode_batch), like the tester's
+            # --recursive flag (multiscale_tester.py:123-132): a file written otherwise could never be read back
+            raise ValueError('auto_recurse needs the single-scale RGB Shared model (num_scales == 1)')
         self.file_writer = file_writer
         self.compare_with_theory = compare_with_theory
         self.times = times if times is not None else _NullTimes()

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
     const float *fuse_b = fuse ? fuse + b * HW * Cf + q * 4 : nullptr;
     float *out_b = out + b * HW * Cf + q * 4;
     const int hw = (int)HW;
-    for (int n = blockIdx.x * ppb + pl; n < hw; n += gridDim.x * ppb) {
+    for (int64_t n = (int64_t)blockIdx.x * ppb + pl; n < hw; n += (int64_t)gridDim.x * ppb) {   // (hw may approach 2^31)
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < DH_MAX_C; ++c) {

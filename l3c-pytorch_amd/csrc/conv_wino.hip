@@ -659,6 +659,9 @@ int l3c_conv_wino(const l3c_conv_desc *d, l3c_stream_t stream) {
                 "Cout must be a multiple of 4 (pixel shuffle: 16): a lane stores four adjacent channels");
     L3C_REQUIRE((d->epilogue & ~(L3C_EPI_RELU | L3C_EPI_RESIDUAL | L3C_EPI_PIXEL_SHUFFLE)) == 0, "unknown epilogue bits");
     L3C_REQUIRE(d->in_coff + d->Cin <= d->in_cstride, "input channel slice out of range");
+    // (the epilogue stores / loads through descriptors whose range is the constant OOB: the hardware check does not bound a slice)
+    L3C_REQUIRE(d->out_coff + ((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? d->Cout / 4 : d->Cout) <= d->out_cstride, "output channel slice out of range");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || d->res_coff + d->Cout <= d->res_cstride, "residual channel slice out of range");
     L3C_REQUIRE(!(d->epilogue & L3C_EPI_RESIDUAL) || d->residual, "residual epilogue without residual pointer");
     L3C_REQUIRE(!((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) && (d->epilogue & L3C_EPI_RESIDUAL)), "pixel shuffle + residual not provided");
     WinoParams p{};

@@ -317,31 +317,51 @@ class MultiscaleTester(object):
         if getattr(self.flags, 'sample', None):
             return self._test_sample(testset)
         test_result = TestResult('bpsp recursive' if self.recursive else 'bpsp')
-        # every auto-crop of every image, grouped by padded shape so that equal shapes share one forward
-        items, groups = [], collections.defaultdict(list)
+        # Streaming evaluation: the auto-crops of the images read so far wait, grouped by padded shape, until a group fills a batch
+        # (equal shapes share one forward) or until its oldest image falls `window` images behind the reader; an image's result is
+        # combined (area-weighted over its crops, auto_crop.py:139-152) as soon as its last crop is through, and reported in input
+        # order like the reference's one-image-at-a-time loop (multiscale_tester.py:322-343).  Memory and latency are bounded by the
+        # window, not by the size of the set.
+        window = 8 * self.max_batch
+        pending = collections.defaultdict(list)        # padded shape -> [(image index, number of sub-pixels, padded crop)]
+        per_img = {}                                   # image index -> [CropLossCombinator, crops still to come, file name]
+        state = {'next': 0}
+
+        def run(shape):
+            chunk, pending[shape] = pending[shape][:self.max_batch], pending[shape][self.max_batch:]
+            if not pending[shape]:
+                del pending[shape]
+            batch = torch.cat([c[2] for c in chunk], dim=0).to('cuda', torch.float32)
+            out = self.blueprint.forward(batch, self.recursive)
+            for (i, n_sub, _), b in zip(chunk, self.per_image_bpsp(out, [c[1] for c in chunk])):
+                per_img[i][0].add(float(b), n_sub)
+                per_img[i][1] -= 1
+
+        def report():
+            while state['next'] in per_img and per_img[state['next']][1] == 0:
+                comb, _, filename = per_img.pop(state['next'])
+                test_result[filename] = comb.get_bpsp()
+                print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, state['next'], test_result.metric_name,
+                                                            test_result.mean()))
+                state['next'] += 1
+
         for i, img_p, raw in self._iter_images(testset.ps):
-            raw = raw.unsqueeze(0)
-            for crop in auto_crop.iter_crops(raw):
-                n_sub = int(np.prod(crop.shape))
+            crops = list(auto_crop.iter_crops(raw.unsqueeze(0)))
+            per_img[i] = [auto_crop.CropLossCombinator(), len(crops), os.path.splitext(os.path.basename(img_p))[0]]
+            for crop in crops:
                 padded = MultiscaleBlueprint.pad(crop, self._padding_fac())
-                groups[tuple(padded.shape[-2:])].append(len(items))
-                items.append({'img': i, 'n_sub': n_sub, 'padded': padded, 'bpsp': None})
-        for shape, idxs in groups.items():
-            for k in range(0, len(idxs), self.max_batch):
-                chunk = idxs[k:k + self.max_batch]
-                batch = torch.cat([items[j]['padded'] for j in chunk], dim=0).to('cuda', torch.float32)
-                out = self.blueprint.forward(batch, self.recursive)
-                bpsp = self.per_image_bpsp(out, [items[j]['n_sub'] for j in chunk])
-                for j, b in zip(chunk, bpsp):
-                    items[j]['bpsp'] = float(b)
-        for i, img_p in enumerate(testset.ps):
-            comb = auto_crop.CropLossCombinator()
-            for it in items:
-                if it['img'] == i:
-                    comb.add(it['bpsp'], it['n_sub'])
-            filename = os.path.splitext(os.path.basename(img_p))[0]
-            test_result[filename] = comb.get_bpsp()
-            print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+                shape = tuple(padded.shape[-2:])
+                pending[shape].append((i, int(np.prod(crop.shape)), padded))
+                if len(pending[shape]) >= self.max_batch:
+                    run(shape)
+            while i - state['next'] >= window and per_img[state['next']][1] > 0:     # the oldest image has waited long enough
+                run(next(sh for sh, items in pending.items() if any(c[0] == state['next'] for c in items)))
+                report()
+            report()
+        while pending:
+            run(next(iter(pending)))
+        report()
+        assert not per_img
         return test_result
 
     # ---- --write_to_files: real files, real round trip ---------------------------------------------------------------------

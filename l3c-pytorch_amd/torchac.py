@@ -46,12 +46,19 @@ def _check_symbols(sym, Lp):
         raise ValueError('symbols must lie in [0, {}], got [{}, {}]'.format(Lp - 2, int(sym.min()), int(sym.max())))
 
 
-def _check_intervals(iv):
+def _check_intervals(table, sym):
     """Encoder precondition on a USER table (torchac.cpp:174-207 divides the range by c_high - c_low): every coded symbol
     needs c_high > c_low.  An empty interval makes the reference emit an undecodable stream; here it could additionally emit
-    more than the 16 bits per symbol the output rows are sized for -- refuse it.  (Word = c_low | (c_high - 1) << 16.)"""
-    lo, hi = iv & 0xFFFF, (iv >> 16) & 0xFFFF
-    if bool((hi < lo).any()):
+    more than the 16 bits per symbol the output rows are sized for -- refuse it.  Checked on the table itself (the packed interval
+    word stores c_high - 1, where an empty interval at 0 is indistinguishable from c_high = 65536): c_low = cdf[sym], c_high =
+    cdf[sym + 1], read as uint16, with 0 standing for 65536 only at the top symbol (torchac.cpp:181)."""
+    N, Lp = table.shape
+    t = table.to(torch.int32) & 0xFFFF
+    s = sym.reshape(-1, 1).long()
+    lo = t.gather(1, s)[:, 0]
+    hi = t.gather(1, s + 1)[:, 0]
+    hi = torch.where(s[:, 0] == Lp - 2, torch.full_like(hi, 65536), hi)
+    if bool((hi <= lo).any()):
         raise ValueError('cdf is not increasing at a coded symbol (c_high <= c_low): the stream would not be decodable')
 
 
@@ -61,8 +68,9 @@ def encode_cdf(cdf, sym):
     if sym.numel() != N:
         raise RuntimeError('cdf has {} rows but {} symbols were given'.format(N, sym.numel()))
     _check_symbols(sym, Lp)
-    iv = ops.intervals_from_table(_dev(cdf).reshape(N, Lp), sym.reshape(1, N), 1, N)
-    _check_intervals(iv)
+    table = _dev(cdf).reshape(N, Lp)
+    _check_intervals(table, sym)
+    iv = ops.intervals_from_table(table, sym.reshape(1, N), 1, N)
     out, nbytes = ops.ac_encode(iv, 1, N)
     return _fetch_stream(out, nbytes)
 
@@ -96,8 +104,8 @@ def encode_logistic_mixture(targets, means, log_scales, logit_probs_softmax, sym
     table, _ = _mixture_table(targets, means, log_scales, logit_probs_softmax)
     sym = _dev(sym.reshape(-1), torch.int16)
     _check_symbols(sym, table.shape[-1])
+    _check_intervals(table.reshape(N, -1), sym)
     iv = ops.intervals_from_table(table.reshape(N, -1), sym.reshape(1, N), 1, N)
-    _check_intervals(iv)
     out, nbytes = ops.ac_encode(iv, 1, N)
     return _fetch_stream(out, nbytes)
 
