@@ -263,6 +263,16 @@ int l3c_conv_wino_set_tiles_per_block(int n);
 int64_t l3c_conv_wino4_packed_words(int Cout, int Cin);
 int l3c_conv_wino4_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
 int l3c_conv_wino4(const l3c_conv_desc *desc_host, l3c_stream_t stream);
+/*
+ * One phase of a STRIDE-2 convolution in its polyphase form (the 5x5 stride-2 padding-2 `down` layers, reference net.py:102,141):
+ *     out[y][x] = sum_{i,j} w[i][j] in[2y-2+i][2x-2+j]  =  sum over the four input phases (a, b) of a 3x3, padding-1, stride-1
+ * convolution of the sub-grid in[2r+a][2c+b] with the phase kernel w_ab[u][v] = w[2u+a][2v+b] (zero where 2u+a or 2v+b > 4) -- each
+ * of which runs on the F(4x4,3x3) kernel: 9 instead of 25 multiplications per output (4 x 36/16).  desc: KS = 3, stride = 2,
+ * dilation 1, Hin / Win = the FULL-resolution input (even), `packed_w` = l3c_conv_wino4_pack_weights of the phase kernel, output
+ * [B][Hin/2][Win/2][..]; epilogue 0 or L3C_EPI_RESIDUAL (the caller accumulates the phases: the first launch carries the bias, the
+ * other three a zero bias and residual == out, in place).
+ */
+int l3c_conv_wino4_phase(const l3c_conv_desc *desc_host, int phase_y, int phase_x, l3c_stream_t stream);
 int l3c_conv_wino4_set_tiles_per_block(int n);
 /*
  * Pointwise (KS == 1, stride 1) convolution Cin -> Cout <= 160 as a pixel x channel GEMM on the fp32 MFMA: the 192 -> Kp layer that

@@ -64,6 +64,8 @@ struct Wino4Params {
     int in_cstride, in_coff, res_cstride, res_coff, out_cstride, out_coff;
     int B, H, W, Cin, Cout;
     int dil, dil_log2;
+    int Ho, Wo;                // output image (== H, W except in the polyphase form)
+    int poly, in_py, in_px;    // polyphase form of a stride-2 convolution: the input is the sub-grid (in_py, in_px) of step 2, the output dense
     W4Div div_groups, div_groups_x, div_chunks;
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
     int tpb, groups_x;
@@ -153,7 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     // three of its pieces out of range.  216 threads fetch, the other 40 idle (offsets out of range, nothing stored).
     const int pf_r0 = tid / (2 * PW), pf_j = tid - pf_r0 * (2 * PW);
     const bool pf_thread = pf_r0 < 6;
-    const int pf_row_b = 6 * dil * p.W * p.in_cstride * 4;                     // six patch rows on, in bytes
+    // input sampling: the sub-grid (py, px) of step dil -- or, for one phase of a stride-2 convolution, (in_py, in_px) of step 2
+    const int istep = p.poly ? 2 : dil, ipy = p.poly ? p.in_py : py, ipx = p.poly ? p.in_px : px;
+    const int pf_row_b = 6 * istep * p.W * p.in_cstride * 4;                   // six patch rows on, in bytes
     const int pf_lds = (pf_r0 * PW + (pf_j >> 1)) * PSR + (pf_j & 1) * 4;       // LDS position of piece 0 (floats); + k * 6 * PW * PSR
     int patch_off;
     auto fresh_tid = [&]() {   // the thread index, recomputed where it is used rarely (kept out of the registers the MFMA loop holds)
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     auto set_patch_tile = [&](int t) {
         const int tf = fresh_tid();
         const int r0 = tf / (2 * PW), j = tf - r0 * (2 * PW);
-        const int iy = py + dil * (sy0 - 1 + r0), ix = px + dil * ((tx_first + t) * OT - 1 + (j >> 1));
+        const int iy = ipy + istep * (sy0 - 1 + r0), ix = ipx + istep * ((tx_first + t) * OT - 1 + (j >> 1));
         const bool ok = r0 < 6 && ix >= 0 && ix < p.W;
         // (iy may be negative: the offset wraps to a huge unsigned value and the load returns zero; iy + 6 k then comes back in range)
         patch_off = ok ? ((iy * p.W + ix) * p.in_cstride + (j & 1) * 4) * 4 : (int)0xC0000000;   // (+ 2 rows: still beyond 2 GB)
@@ -215,13 +219,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
 
     // ---- output addressing: ONE uniform descriptor at the block's first output row, a per-lane byte offset, uniform offsets
     constexpr int S = SHUFFLE ? 2 : 1;
-    const int col_b = S * dil * p.out_cstride * 4, row_b = S * dil * (S * p.W) * p.out_cstride * 4;   // one conv pixel / row on
-    const int rcol_b = dil * p.res_cstride * 4, rrow_b = dil * p.W * p.res_cstride * 4;
+    const int col_b = S * dil * p.out_cstride * 4, row_b = S * dil * (S * p.Wo) * p.out_cstride * 4;   // one conv pixel / row on
+    const int rcol_b = dil * p.res_cstride * 4, rrow_b = dil * p.Wo * p.res_cstride * 4;
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.out + (((size_t)b * (S * p.H) + S * (py + dil * sy0)) * (S * p.W) + S * px) * p.out_cstride + p.out_coff +
+        p.out + (((size_t)b * (S * p.Ho) + S * (py + dil * sy0)) * (S * p.Wo) + S * px) * p.out_cstride + p.out_coff +
             (SHUFFLE ? chunk_o * 16 : chunk_o * 64), 0, OOB, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float *>(RES ? p.res + (((size_t)b * p.H + py + dil * sy0) * p.W + px) * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias),
+        const_cast<float *>(RES ? p.res + (((size_t)b * p.Ho + py + dil * sy0) * p.Wo + px) * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias),
         0, RES ? OOB : 0, 0x00020000);
 
     auto body = [&](auto th_c) __attribute__((always_inline)) {
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             int o_lane, r_lane = 0;
             if constexpr (SHUFFLE)   // conv channel co -> output pixel (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2: lane
                                      // (pixel, sub-pixel c4) stores the four output channels of this wavefront's 16 conv channels
-                o_lane = 4 * q2 * row_b + j2 * col_b + ((c4 >> 1) * (2 * p.W) + (c4 & 1)) * p.out_cstride * 4 + wave * 16;
+                o_lane = 4 * q2 * row_b + j2 * col_b + ((c4 >> 1) * (2 * p.Wo) + (c4 & 1)) * p.out_cstride * 4 + wave * 16;
             else
                 o_lane = 4 * q2 * row_b + j2 * col_b + (wave * 16 + c4 * 4) * 4;
             if constexpr (RES) r_lane = 4 * q2 * rrow_b + j2 * rcol_b + (wave * 16 + c4 * 4) * 4;
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             float *w_dst = win + q * 80 + (SHUFFLE ? (n & 3) * 4 + (n >> 2) : n);   // shuffle: channels of one sub-pixel adjacent
             const float *w_src = win + q2 * 80 + j2 * 16 + c4 * 4;
             auto lane_off = [&](int base, int r, int i) {
-                const bool ok = lane_ok && oy_l + dil * i < p.H && ox_l + dil * 4 * r < p.W;
+                const bool ok = lane_ok && oy_l + dil * i < p.Ho && ox_l + dil * 4 * r < p.Wo;
                 return ok ? base : OOB;
             };
             f32x4 resv[3];
@@ -528,10 +532,25 @@ int l3c_conv_wino4_pack_weights(const float *w_oihw, int Cout, int Cin, float *p
     return l3c::check_launch("pack_wino4_kernel");
 }
 
+static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int phase_x, l3c_stream_t stream);
+
 int l3c_conv_wino4(const l3c_conv_desc *d, l3c_stream_t stream) {
     L3C_REQUIRE(d, "null descriptor");
-    L3C_REQUIRE(d->in && d->packed_w && d->bias && d->out, "null pointer in descriptor");
     L3C_REQUIRE(d->KS == 3 && d->stride == 1, "Winograd F(4x4,3x3): 3x3, stride 1 only");
+    return conv_wino4_launch(d, 0, 0, 0, stream);
+}
+
+int l3c_conv_wino4_phase(const l3c_conv_desc *d, int phase_y, int phase_x, l3c_stream_t stream) {
+    L3C_REQUIRE(d, "null descriptor");
+    L3C_REQUIRE(d->KS == 3 && d->stride == 2 && d->dilation == 1, "polyphase form: 3x3 phase kernel, stride 2, no dilation");
+    L3C_REQUIRE((phase_y == 0 || phase_y == 1) && (phase_x == 0 || phase_x == 1), "phase must be 0 or 1");
+    L3C_REQUIRE(d->Hin % 2 == 0 && d->Win % 2 == 0, "polyphase form: even input size");
+    L3C_REQUIRE(!(d->epilogue & (L3C_EPI_PIXEL_SHUFFLE | L3C_EPI_RELU)), "polyphase form: bias (+ residual) only");
+    return conv_wino4_launch(d, 1, phase_y, phase_x, stream);
+}
+
+static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int phase_x, l3c_stream_t stream) {
+    L3C_REQUIRE(d->in && d->packed_w && d->bias && d->out, "null pointer in descriptor");
     L3C_REQUIRE(d->dilation == 1 || d->dilation == 2 || d->dilation == 4, "dilation must be 1, 2 or 4");
     L3C_REQUIRE(d->dilation == 1 || !(d->epilogue & L3C_EPI_PIXEL_SHUFFLE), "pixel shuffle with dilation not provided");
     L3C_REQUIRE(d->B > 0 && d->Hin > 0 && d->Win > 0 && d->Cout > 0, "bad shape");
@@ -559,10 +578,12 @@ int l3c_conv_wino4(const l3c_conv_desc *d, l3c_stream_t stream) {
     p.res_cstride = d->res_cstride;  p.res_coff = d->res_coff;
     p.out_cstride = d->out_cstride;  p.out_coff = d->out_coff;
     p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = d->Cin;  p.Cout = d->Cout;
+    p.poly = poly;  p.in_py = phase_y;  p.in_px = phase_x;
+    p.Ho = poly ? d->Hin / 2 : d->Hin;  p.Wo = poly ? d->Win / 2 : d->Win;
     p.dil = d->dilation;
     p.dil_log2 = d->dilation == 4 ? 2 : d->dilation == 2 ? 1 : 0;
-    p.tiles_x = ((p.W + p.dil - 1) / p.dil + OT - 1) / OT;   // tiles of the (largest) sub-grid
-    p.tiles_y = ((p.H + p.dil - 1) / p.dil + OT - 1) / OT;
+    p.tiles_x = ((p.Wo + p.dil - 1) / p.dil + OT - 1) / OT;   // tiles of the (largest) sub-grid
+    p.tiles_y = ((p.Ho + p.dil - 1) / p.dil + OT - 1) / OT;
     p.n_chunks_o = (p.Cout + 63) / 64;
     const int64_t rows = (int64_t)p.tiles_y * p.dil * p.dil * p.n_chunks_o * p.B;
     const int tpb_set = g_w4_tpb.load(std::memory_order_relaxed);

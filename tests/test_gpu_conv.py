@@ -45,7 +45,7 @@ def test_conv_mfma_vs_torch(KS, stride, dil, Cin, Cout, B, H, W):
     b = torch.randn(Cout, generator=g)
     ref = _ref_conv(x, w, b, stride, dil)
     layer = ops.PackedConv(w, b, stride=stride, dilation=dil)
-    IMPL = 'gemm' if KS == 3 else 'mfma'     # 3x3: the implicit-GEMM kernel (the product dispatches 3x3 layers to Winograd)
+    IMPL = 'gemm' if KS in (3, 5) else 'mfma'     # 3x3, 5x5: the implicit-GEMM kernel (the product dispatches them to Winograd forms)
     got = ops.conv(_nhwc(x).cuda(), layer, impl=IMPL).cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item()
@@ -460,3 +460,30 @@ def test_winograd_f4_channel_slices_and_tiles_per_block():
         lib.l3c_conv_wino4_set_tiles_per_block(prev)
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+@pytest.mark.parametrize('B,H,W,Cout', [(1, 32, 32, 64), (2, 46, 70, 64), (1, 128, 192, 64), (3, 8, 6, 64), (1, 2, 2, 64), (2, 64, 96, 120)])
+def test_conv5x5_stride2_polyphase_vs_implicit_gemm_and_fp64(B, H, W, Cout):
+    """5x5 stride 2 padding 2 as four 3x3 polyphase convolutions on the F(4x4,3x3) kernel (l3c_conv_wino4_phase, accumulated in
+    place) against the implicit-GEMM 5x5 kernel and fp64: within 1e-4 for unit-scale data; deterministic; output into a channel
+    slice of a wider NaN-poisoned tensor."""
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(H * 7 + W)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w = torch.randn(Cout, 64, 5, 5, generator=g) / 40
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=2)
+    layer = ops.PackedConv(w, b, stride=2)
+    xd = _nhwc(x).cuda()
+    got = ops.conv(xd, layer, impl='poly5').cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    print('polyphase 5x5 s2 max |err| vs fp64: {:.3g}'.format(err))
+    assert err < 1e-4, err
+    gemm = ops.conv(xd, layer, impl='gemm').cpu().permute(0, 3, 1, 2)
+    assert (gemm.double() - ref).abs().max().item() < 3e-5
+    assert torch.equal(ops.conv(xd, layer, impl='poly5').cpu().permute(0, 3, 1, 2), got)
+    wide = torch.full((B, H // 2, W // 2, Cout + 8), float('nan'), device='cuda')
+    ops.conv(xd, layer, out=wide, out_coff=4, impl='poly5')
+    assert torch.equal(wide[..., 4:4 + Cout].cpu().permute(0, 3, 1, 2), got)
+    assert bool(torch.isnan(wide[..., :4]).all()) and bool(torch.isnan(wide[..., 4 + Cout:]).all())
