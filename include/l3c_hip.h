@@ -273,6 +273,13 @@ int l3c_conv_wino4(const l3c_conv_desc *desc_host, l3c_stream_t stream);
  * other three a zero bias and residual == out, in place).
  */
 int l3c_conv_wino4_phase(const l3c_conv_desc *desc_host, int phase_y, int phase_x, l3c_stream_t stream);
+/*
+ * The same 5x5 stride-2 padding-2 convolution with ALL FOUR phases in one launch: the kernel's chunk sequence runs through the phases
+ * (input channels of phase (0,0), then (0,1), (1,0), (1,1)), so there is one output transform and no read-modify-write of the
+ * output.  desc: KS = 5, stride = 2, Cin = the input's channels, bias-only epilogue; `packed_w` = l3c_conv_wino4_pack_weights(w_cat,
+ * Cout, 4 * Cin) of the four phase kernels concatenated along the INPUT-channel axis, phase-major: w_cat[:, (2a+b) Cin + ci] = w_ab[:, ci].
+ */
+int l3c_conv_wino4_stride2(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 int l3c_conv_wino4_set_tiles_per_block(int n);
 /*
  * Pointwise (KS == 1, stride 1) convolution Cin -> Cout <= 160 as a pixel x channel GEMM on the fp32 MFMA: the 192 -> Kp layer that

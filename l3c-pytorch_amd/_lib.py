@@ -86,6 +86,7 @@ PROTOTYPES = {
     'l3c_conv_wino4_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_wino4': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_wino4_phase': (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int, c_vp]),
+    'l3c_conv_wino4_stride2': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_wino4_set_tiles_per_block': (c_int, [c_int]),
     'l3c_conv_pw_packed_words': (c_i64, [c_int, c_int]),
     'l3c_conv_pw_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),

@@ -66,6 +66,7 @@ struct Wino4Params {
     int dil, dil_log2;
     int Ho, Wo;                // output image (== H, W except in the polyphase form)
     int poly, in_py, in_px;    // polyphase form of a stride-2 convolution: the input is the sub-grid (in_py, in_px) of step 2, the output dense
+    int poly_ncp;              // > 0: ALL FOUR phases in this launch -- the chunk sequence runs through the phases, poly_ncp chunks each
     W4Div div_groups, div_groups_x, div_chunks;
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
     int tpb, groups_x;
@@ -156,7 +157,10 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const int pf_r0 = tid / (2 * PW), pf_j = tid - pf_r0 * (2 * PW);
     const bool pf_thread = pf_r0 < 6;
     // input sampling: the sub-grid (py, px) of step dil -- or, for one phase of a stride-2 convolution, (in_py, in_px) of step 2
-    const int istep = p.poly ? 2 : dil, ipy = p.poly ? p.in_py : py, ipx = p.poly ? p.in_px : px;
+    // -- or, with poly_ncp > 0, all four phases one after the other: the chunk sequence of a tile is (phase 0: poly_ncp chunks of the
+    // input's channels, phase 1: ...), the weights are those of a convolution with 4 Cin input channels (phase-major)
+    const int istep = p.poly ? 2 : dil;
+    const int ncp = p.poly_ncp > 0 ? p.poly_ncp : n_cc, n_phase = p.poly_ncp > 0 ? 4 : 1;
     const int pf_row_b = 6 * istep * p.W * p.in_cstride * 4;                   // six patch rows on, in bytes
     const int pf_lds = (pf_r0 * PW + (pf_j >> 1)) * PSR + (pf_j & 1) * 4;       // LDS position of piece 0 (floats); + k * 6 * PW * PSR
     int patch_off;
@@ -165,22 +169,27 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         asm volatile("" : "+s"(m));
         return wave * 64 + (int)__builtin_amdgcn_mbcnt_hi(m, __builtin_amdgcn_mbcnt_lo(m, 0u));
     };
-    auto set_patch_tile = [&](int t) {
+    auto set_patch_tile = [&](int t, int ph = 0) {
         const int tf = fresh_tid();
         const int r0 = tf / (2 * PW), j = tf - r0 * (2 * PW);
+        const int ipy = p.poly ? (p.poly_ncp > 0 ? ph >> 1 : p.in_py) : py, ipx = p.poly ? (p.poly_ncp > 0 ? ph & 1 : p.in_px) : px;
         const int iy = ipy + istep * (sy0 - 1 + r0), ix = ipx + istep * ((tx_first + t) * OT - 1 + (j >> 1));
         const bool ok = r0 < 6 && ix >= 0 && ix < p.W;
         // (iy may be negative: the offset wraps to a huge unsigned value and the load returns zero; iy + 6 k then comes back in range)
         patch_off = ok ? ((iy * p.W + ix) * p.in_cstride + (j & 1) * 4) * 4 : (int)0xC0000000;   // (+ 2 rows: still beyond 2 GB)
     };
-    int pf_tile = 0, pf_cc = 0;   // the prefetch pointer: (tile, chunk) of the next patch to fetch
+    int pf_tile = 0, pf_ph = 0, pf_cc = 0;   // the prefetch pointer: (tile, phase, chunk of the phase) of the next patch to fetch
     auto pf_advance = [&]() {
-        if (++pf_cc == n_cc) {
-            if (pf_tile + 1 < n_t) {
+        if (++pf_cc == ncp) {
+            if (pf_ph + 1 < n_phase) {
                 pf_cc = 0;
-                set_patch_tile(++pf_tile);
+                set_patch_tile(pf_tile, ++pf_ph);
+            } else if (pf_tile + 1 < n_t) {
+                pf_cc = 0;
+                pf_ph = 0;
+                set_patch_tile(++pf_tile, 0);
             } else {
-                pf_cc = n_cc - 1;   // past the block's last chunk: the loads stay unconditional, their data is never used
+                pf_cc = ncp - 1;   // past the block's last chunk: the loads stay unconditional, their data is never used
             }
         }
     };
@@ -532,7 +541,7 @@ int l3c_conv_wino4_pack_weights(const float *w_oihw, int Cout, int Cin, float *p
     return l3c::check_launch("pack_wino4_kernel");
 }
 
-static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int phase_x, l3c_stream_t stream);
+static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int phase_x, l3c_stream_t stream);   // poly: 0 no, 1 one phase, 2 all four
 
 int l3c_conv_wino4(const l3c_conv_desc *d, l3c_stream_t stream) {
     L3C_REQUIRE(d, "null descriptor");
@@ -547,6 +556,14 @@ int l3c_conv_wino4_phase(const l3c_conv_desc *d, int phase_y, int phase_x, l3c_s
     L3C_REQUIRE(d->Hin % 2 == 0 && d->Win % 2 == 0, "polyphase form: even input size");
     L3C_REQUIRE(!(d->epilogue & (L3C_EPI_PIXEL_SHUFFLE | L3C_EPI_RELU)), "polyphase form: bias (+ residual) only");
     return conv_wino4_launch(d, 1, phase_y, phase_x, stream);
+}
+
+int l3c_conv_wino4_stride2(const l3c_conv_desc *d, l3c_stream_t stream) {
+    L3C_REQUIRE(d, "null descriptor");
+    L3C_REQUIRE(d->KS == 5 && d->stride == 2 && d->dilation == 1, "fused polyphase form: 5x5, stride 2, padding 2");
+    L3C_REQUIRE(d->Hin % 2 == 0 && d->Win % 2 == 0, "polyphase form: even input size");
+    L3C_REQUIRE(d->epilogue == 0, "fused polyphase form: bias only");
+    return conv_wino4_launch(d, 2, 0, 0, stream);
 }
 
 static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int phase_x, l3c_stream_t stream) {
@@ -577,8 +594,8 @@ static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int 
     p.in_cstride = d->in_cstride;  p.in_coff = d->in_coff;
     p.res_cstride = d->res_cstride;  p.res_coff = d->res_coff;
     p.out_cstride = d->out_cstride;  p.out_coff = d->out_coff;
-    p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = d->Cin;  p.Cout = d->Cout;
-    p.poly = poly;  p.in_py = phase_y;  p.in_px = phase_x;
+    p.B = d->B;  p.H = d->Hin;  p.W = d->Win;  p.Cin = poly == 2 ? 4 * d->Cin : d->Cin;  p.Cout = d->Cout;
+    p.poly = poly != 0;  p.in_py = phase_y;  p.in_px = phase_x;  p.poly_ncp = poly == 2 ? d->Cin / CK : 0;
     p.Ho = poly ? d->Hin / 2 : d->Hin;  p.Wo = poly ? d->Win / 2 : d->Win;
     p.dil = d->dilation;
     p.dil_log2 = d->dilation == 4 ? 2 : d->dilation == 2 ? 1 : 0;

@@ -15,6 +15,7 @@ _CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
 _CONV_WINO4 = os.environ.get('L3C_CONV_WINO4', '1') != '0'
 # 5x5 / stride 2 layers (the encoders' `down`) run as four 3x3 polyphase convolutions on the F(4x4,3x3) kernel unless L3C_CONV_POLY5=0
 _CONV_POLY5 = os.environ.get('L3C_CONV_POLY5', '1') != '0'
+_CONV_POLY5_FUSED = os.environ.get('L3C_CONV_POLY5_FUSED', '1') != '0'   # all four phases in one launch (0: four accumulating launches)
 # 1x1 layers with Cin % 64 == 0 and Cout <= 160 (the 192 -> Kp classifier output) run on the pointwise kernel (csrc/conv_pw.hip)
 # unless L3C_CONV_PW=0
 _CONV_PW = os.environ.get('L3C_CONV_PW', '1') != '0'
@@ -69,6 +70,15 @@ class PackedConv(object):
                     call('l3c_conv_wino4_pack_weights', ptr(wp), self.Cout, self.Cin, ptr(packed), stream())
                     self.packed_poly.append(packed)
             self.zero_bias = torch.zeros(self.Cout, dtype=torch.float32, device='cuda')
+            # all four phases in ONE launch (l3c_conv_wino4_stride2): the phase kernels concatenated along the input-channel axis
+            w_cat = torch.zeros(self.Cout, 4 * self.Cin, 3, 3, dtype=torch.float32, device='cuda')
+            for a in (0, 1):
+                for b in (0, 1):
+                    sub = self.weight[:, :, a::2, b::2]
+                    w_cat[:, (2 * a + b) * self.Cin:(2 * a + b + 1) * self.Cin, :sub.shape[2], :sub.shape[3]] = sub
+            n4 = _lib.load().l3c_conv_wino4_packed_words(self.Cout, 4 * self.Cin)
+            self.packed_poly_fused = torch.empty(n4, dtype=torch.float32, device='cuda')
+            call('l3c_conv_wino4_pack_weights', ptr(w_cat), self.Cout, 4 * self.Cin, ptr(self.packed_poly_fused), stream())
 
         self.packed_pw = None
         if _CONV_PW and self.KS == 1 and stride == 1 and self.Cin % 64 == 0 and self.Cout <= 160:
@@ -102,13 +112,13 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
                layer.Cout % (16 if pixel_shuffle else 4) == 0 and
                not (pixel_shuffle and (relu or residual is not None or layer.dilation != 1)))
     # impl: 'mfma' = the product's dispatch; 'wino4' / 'wino2' / 'gemm' force one kernel (tests, probes); 'direct' = VALU cross-check
-    poly = ((impl == 'poly5' or (impl == 'mfma' and _CONV_POLY5 and _CONV_WINO4)) and getattr(layer, 'packed_poly', None) is not None and
+    poly = ((impl in ('poly5', 'poly5x4') or (impl == 'mfma' and _CONV_POLY5 and _CONV_WINO4)) and getattr(layer, 'packed_poly', None) is not None and
             H % 2 == 0 and W % 2 == 0 and _aligned(out, out_coff) and residual is None and not relu and not pixel_shuffle and
             x.data_ptr() % 16 == 0 and cstride % 4 == 0 and in_coff % 4 == 0 and H * W * cstride * 4 < 0x7ffffff0)
-    if impl == 'poly5':
+    if impl in ('poly5', 'poly5x4'):
         assert poly, 'this layer has no polyphase form'
     if poly:
-        return _conv_poly5(x, layer, out, in_coff, out_coff)
+        return _conv_poly5(x, layer, out, in_coff, out_coff, fused=(impl != 'poly5x4' and _CONV_POLY5_FUSED))
     wino4 = (impl == 'wino4' or (impl == 'mfma' and _CONV_WINO4)) and layer.packed_wino4 is not None and wino_ok
     wino = not wino4 and impl in ('mfma', 'wino2') and layer.packed_wino is not None and wino_ok
     if impl in ('wino4', 'wino2'):
@@ -151,14 +161,23 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     return out
 
 
-def _conv_poly5(x, layer, out, in_coff, out_coff):
-    """5x5 stride 2 as four phase launches of the F(4x4,3x3) kernel accumulating into `out` (the first carries the bias)."""
+def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True):
+    """5x5 stride 2 in polyphase form on the F(4x4,3x3) kernel: all four phases in one launch, or (fused=False) four phase launches
+    accumulating into `out` (the first carries the bias)."""
     B, H, W, cstride = x.shape
     e0 = e1 = None
     if PROFILE is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    for k, (a, b) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+    if fused:
+        d = ConvDesc()
+        d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
+        d.packed_w, d.bias, d.residual = ptr(layer.packed_poly_fused), ptr(layer.bias), None
+        d.out, d.out_cstride, d.out_coff = ptr(out, torch.float32), out.shape[-1], out_coff
+        d.B, d.Hin, d.Win, d.Cin, d.Cout = B, H, W, layer.Cin, layer.Cout
+        d.KS, d.stride, d.dilation, d.epilogue = 5, 2, 1, 0
+        call('l3c_conv_wino4_stride2', d, stream())
+    for k, (a, b) in enumerate(() if fused else ((0, 0), (0, 1), (1, 0), (1, 1))):
         d = ConvDesc()
         d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
         d.packed_w = ptr(layer.packed_poly[k])
@@ -173,7 +192,7 @@ def _conv_poly5(x, layer, out, in_coff, out_coff):
     if PROFILE is not None:
         e1.record()
         nbytes = 4.0 * B * (H * W * layer.Cin + (H // 2) * (W // 2) * layer.Cout)
-        PROFILE.append(('conv k5 s2 (4 x F(4x4,3x3) phases)', 2.0 * B * (H // 2) * (W // 2) * layer.Cout * layer.Cin * 25, nbytes, e0, e1))
+        PROFILE.append(('conv k5 s2 (4 F(4x4,3x3) phases)', 2.0 * B * (H // 2) * (W // 2) * layer.Cout * layer.Cin * 25, nbytes, e0, e1))
     return out
 
 

@@ -483,6 +483,8 @@ def test_conv5x5_stride2_polyphase_vs_implicit_gemm_and_fp64(B, H, W, Cout):
     gemm = ops.conv(xd, layer, impl='gemm').cpu().permute(0, 3, 1, 2)
     assert (gemm.double() - ref).abs().max().item() < 3e-5
     assert torch.equal(ops.conv(xd, layer, impl='poly5').cpu().permute(0, 3, 1, 2), got)
+    x4 = ops.conv(xd, layer, impl='poly5x4').cpu().permute(0, 3, 1, 2)     # the four-launch form (accumulated in place)
+    assert (x4.double() - ref).abs().max().item() < 1e-4
     wide = torch.full((B, H // 2, W // 2, Cout + 8), float('nan'), device='cuda')
     ops.conv(xd, layer, out=wide, out_coff=4, impl='poly5')
     assert torch.equal(wide[..., 4:4 + Cout].cpu().permute(0, 3, 1, 2), got)
