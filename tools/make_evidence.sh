@@ -4,7 +4,7 @@
 #     /usr/local/graft/bin/gpurun --timeout 2400 -- tools/make_evidence.sh      # on the GPU box: writes gpurun_out/evidence/
 #     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r03_*
 #
-# Steps on the GPU box: (1) the default bench line; (2) the 768x512 parity suite (tests/test_gpu_headline.py writes the measured
+# Steps on the GPU box: (1) the default bench line (after the PMC passes, so that it carries their table); (2) the 768x512 parity suite (tests/test_gpu_headline.py writes the measured
 # errors); (3) rocprofv3 --kernel-trace --stats over the same bench command; (4) three separate rocprofv3 --pmc passes (FETCH_SIZE /
 # WRITE_SIZE / SQ + GRBM counters; never combined with a trace domain) reduced by tools/pmc_bench.py and stamped with the hash of the
 # kernel sources; (5) the other two configs at full size.
@@ -29,8 +29,8 @@ export TMPDIR=/tmp
 E=$PWD/gpurun_out/evidence
 rm -rf "$E"; mkdir -p "$E"
 LIGHT="--no-cpu-baseline --no-parity --no-extra-legs"
-timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err
 timeout 900 python -m pytest tests/test_gpu_headline.py -q > $E/pytest_headline.log 2>&1
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $E/smoke.log 2>&1; tail -2 $E/smoke.log
 cp gpurun_out/parity_768x512_*.json $E/
 timeout 600 rocprofv3 --kernel-trace --stats -d $E/stats -o run -- python bench.py $LIGHT > $E/bench_profiled_run.json 2> $E/rocprof_stats.err
 DB=$(find $E/stats -name '*.db' | head -1)
@@ -41,6 +41,8 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE -d $E/pmc/write -o run --output-format cs
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
     -d $E/pmc/sq -o run --output-format csv -- python bench.py $PMCARGS > /dev/null 2> $E/pmc_sq.err
 python tools/pmc_bench.py $E/pmc 128 > $E/pmc_bench.json
+cp $E/pmc_bench.json profiles/r03_pmc_bench.json      # (the box's copy: the bench line below then reports it as current)
+timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err
 timeout 900 python bench.py --config dataset > $E/bench_dataset.json 2> $E/bench_dataset.err
 timeout 600 python bench.py --config large > $E/bench_large.json 2> $E/bench_large.err
 # keep the merge-back small: the raw traces stay on the box
