@@ -1,10 +1,12 @@
 // conv_wino4.hip -- 3x3 / stride 1 convolution (dilation 1, 2, 4) by Winograd F(4x4, 3x3) on the fp32 MFMA.
 //
 // 4x fewer multiplications than the direct form and 1.78x fewer than F(2x2,3x3) (conv_wino.hip): every 4x4 output tile is
-//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A,        d the 6x6 input tile, interpolation points {0, +-1, +-2, inf}:
-//     B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
-//     G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
-//     A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+//     Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A,        d the 6x6 input tile, interpolation points {0, 1, -1, 1/2, -2, inf}
+//     (the set with the smallest fp32 error for F(4,3): half that of the textbook {0, +-1, +-2, inf}, measured on the whole forward:
+//     profiles/r03_wino_f43_numerics.log; the transforms cost ~1.7x the additions, which this kernel has room for):
+//     B^T = [2 -3 -4 3 2 0; 0 -2 1 5 2 0; 0 -2 5 -1 -2 0; 0 2 1 -2 -1 0; 0 1 -2 -1 2 0; 0 2 -3 -4 3 2]
+//     G   = [1/2 0 0; 1/6 1/6 1/6; 1/6 -1/6 1/6; 16/15 8/15 4/15; 1/30 -1/15 2/15; 0 0 1/2]
+//     A^T = [1 1 1 1 1 0; 0 1 -1 1/2 -2 0; 0 1 1 1/4 4 0; 0 1 -1 1/8 -8 1]
 // The sum over input channels is, for each of the 36 positions (xi, nu) of the transformed tile, a GEMM
 //     M[xi,nu] (tiles x Cout) = V[xi,nu] (tiles x Cin) * U[xi,nu] (Cin x Cout)
 // on v_mfma_f32_16x16x4_f32.  fp32 throughout; the error against the direct convolution was measured BEFORE the kernel was
@@ -99,23 +101,22 @@ __device__ __forceinline__ int xcd_remap4(int bid, int total) {
 
 // one 6-vector through B^T (rows of the input transform), all six outputs
 __device__ __forceinline__ void bt6(const float (&w)[6], float (&o)[6]) {
-    o[0] = __builtin_fmaf(4.0f, w[0], __builtin_fmaf(-5.0f, w[2], w[4]));
-    const float a = __builtin_fmaf(-4.0f, w[2], w[4]), b = __builtin_fmaf(-4.0f, w[1], w[3]);
-    o[1] = a + b;
-    o[2] = a - b;
-    const float c = w[4] - w[2], d = w[3] - w[1];
-    o[3] = __builtin_fmaf(2.0f, d, c);
-    o[4] = __builtin_fmaf(-2.0f, d, c);
-    o[5] = __builtin_fmaf(4.0f, w[1], __builtin_fmaf(-5.0f, w[3], w[5]));
+    o[0] = __builtin_fmaf(2.0f, w[0] + w[4], __builtin_fmaf(3.0f, w[3] - w[1], -4.0f * w[2]));
+    o[1] = __builtin_fmaf(2.0f, w[4], __builtin_fmaf(5.0f, w[3], __builtin_fmaf(-2.0f, w[1], w[2])));
+    o[2] = __builtin_fmaf(-2.0f, w[4], __builtin_fmaf(-2.0f, w[1], __builtin_fmaf(5.0f, w[2], -w[3])));
+    const float p = w[1] - w[3], q = w[2] - w[4];
+    o[3] = __builtin_fmaf(2.0f, p, q);
+    o[4] = __builtin_fmaf(-2.0f, q, p);
+    o[5] = __builtin_fmaf(2.0f, w[1] + w[5], __builtin_fmaf(3.0f, w[4] - w[2], -4.0f * w[3]));
 }
 
 // one 6-vector through A^T (output transform), four outputs
 __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
-    const float s1 = m1 + m2, d1 = m1 - m2, s2 = m3 + m4, d2 = m3 - m4;
-    y[0] = (m0 + s1) + s2;
-    y[1] = __builtin_fmaf(2.0f, d2, d1);
-    y[2] = __builtin_fmaf(4.0f, s2, s1);
-    y[3] = __builtin_fmaf(8.0f, d2, d1) + m5;
+    const float s1 = m1 + m2, d1 = m1 - m2;
+    y[0] = (m0 + s1) + (m3 + m4);
+    y[1] = d1 + __builtin_fmaf(-2.0f, m4, 0.5f * m3);
+    y[2] = s1 + __builtin_fmaf(4.0f, m4, 0.25f * m3);
+    y[3] = (d1 + __builtin_fmaf(-8.0f, m4, 0.125f * m3)) + m5;
 }
 
 // Development probes (csrc/build.py --variant NAME "-DL3C_W4_PROBE=N"; results are WRONG, only the time means something): bit 0 no
@@ -247,17 +248,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         };
         auto tr_col = [&](int col) {
             const float(&l)[5] = L[col & 1];
-            const float x = __builtin_fmaf(4.0f, l[0], __builtin_fmaf(-5.0f, l[2], l[4]));
-            if constexpr (TH == 0) {   // xi = 0, 1, 2 from raw rows 0 .. 4
-                const float a = __builtin_fmaf(-4.0f, l[2], l[4]), bb = __builtin_fmaf(-4.0f, l[1], l[3]);
-                T[0][col] = x;
-                T[1][col] = a + bb;
-                T[2][col] = a - bb;
+            if constexpr (TH == 0) {   // xi = 0, 1, 2 from raw rows 0 .. 4 (l[i] = row i)
+                T[0][col] = __builtin_fmaf(2.0f, l[0] + l[4], __builtin_fmaf(3.0f, l[3] - l[1], -4.0f * l[2]));
+                T[1][col] = __builtin_fmaf(2.0f, l[4], __builtin_fmaf(5.0f, l[3], __builtin_fmaf(-2.0f, l[1], l[2])));
+                T[2][col] = __builtin_fmaf(-2.0f, l[4], __builtin_fmaf(-2.0f, l[1], __builtin_fmaf(5.0f, l[2], -l[3])));
             } else {                   // xi = 3, 4, 5 from raw rows 1 .. 5 (l[i] = row 1 + i)
-                const float a = l[3] - l[1], d = l[2] - l[0];
-                T[0][col] = __builtin_fmaf(2.0f, d, a);
-                T[1][col] = __builtin_fmaf(-2.0f, d, a);
-                T[2][col] = x;
+                const float pp_ = l[0] - l[2], qq_ = l[1] - l[3];
+                T[0][col] = __builtin_fmaf(2.0f, pp_, qq_);
+                T[1][col] = __builtin_fmaf(-2.0f, qq_, pp_);
+                T[2][col] = __builtin_fmaf(2.0f, l[0] + l[4], __builtin_fmaf(3.0f, l[3] - l[1], -4.0f * l[2]));
             }
         };
         float R[6];
@@ -315,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         // one chunk in four -- a pixel's 32 channels share a 128-byte line -- and L2 latency otherwise), and with four pairs of
         // lookahead that stalled the wave in every chunk [probe: no patch fetch -15 %].  So the B operands of pairs 3..9 of the NEXT
         // chunk are fetched in one burst (seven register quads: the registers the input transform has just released -- it runs in
-        // pairs 10..15, the burst is consumed by pair 9) IMMEDIATELY BEFORE the patch fetch at pair 16: the first B load issued behind
+        // pairs 7..15, the burst is consumed by pair 9; [measured: columns in pairs 10..12 two at a time 171, 6..11 168, 7..12 174 MPix/s]) IMMEDIATELY BEFORE the patch fetch at pair 16: the first B load issued behind
         // the patch is the one of pair 10 at pair 6 of the next chunk, needed at pair 10 -- the patch has 12 pairs' time to arrive.
         // KIND 0: first chunk of a tile (all its B operands come through the ring: the chunk before it was the last of the previous
         // tile or the prologue), 1: middle, 2: last chunk of a tile (no burst: the output transform needs the registers).
@@ -347,25 +346,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                     a_ring[0] = *reinterpret_cast<const f32x4 *>(a_nxt);
                 }
                 L3C_W4_MFMA(2 * pp, A[0], Bv[0], true)
-                if (TR && pp >= 10 && pp <= 12) tr_load(r_src, 2 * (pp - 10));
+                if (TR && pp >= 7 && pp <= 12) tr_load(r_src, pp - 7);        // one patch column per pair, pairs 7..12 (the burst's registers
+                                                                              // free up as its pairs 3..9 are consumed)
                 if (TR && pp >= 13 && pp <= 15) tr_row(pp - 13);
                 if (ST && pp == 16) store_piece(r_dst, 0, stage[0]);
                 if (ST && pp == 16) store_piece(r_dst, 1, stage[1]);
                 L3C_W4_MFMA(2 * pp + 1, A[2], Bv[2], true)
-                if (TR && pp >= 10 && pp <= 12) tr_load(r_src, 2 * (pp - 10) + 1);
                 if (ST && pp == 16) store_piece(r_dst, 2, stage[2]);
                 if (LB && !LAST && pp == 15) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) b_burst[k] = fetch_b(cc_b, 3 + k);
                 }
                 L3C_W4_MFMA(2 * pp, A[1], Bv[1], false)
-                if (TR && pp >= 10 && pp <= 12) tr_col(2 * (pp - 10));
+                if (TR && pp >= 7 && pp <= 12) tr_col(pp - 7);
                 if (TR && pp >= 13 && pp <= 15) tr_write(v_next, pp - 13);
                 L3C_W4_MFMA(2 * pp + 1, A[3], Bv[3], false)
                 // (the rings are reloaded behind the pair's last MFMA: A and Bv are references into them)
                 if (pp < NPP - 2) a_ring[pp & 1] = *reinterpret_cast<const f32x4 *>(a_cur + (pp + 2) * VPP);
                 if (pp == NPP - 1) a_ring[1] = *reinterpret_cast<const f32x4 *>(a_nxt + VPP);
-                if (TR && pp >= 10 && pp <= 12) tr_col(2 * (pp - 10) + 1);
                 // the ring: pair pp + 4 -- of this chunk, or (numbered on) of the next one, whose pairs 3..9 come from the burst
                 if constexpr (LB) {
                     const int nxt = pp + 4;
@@ -497,8 +495,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
 // U[position (xi = pp / 3, nu = 2 (pp % 3) + e)][co = chunk * 64 + wave * 16 + n][ci = cc * 8 + 2 kq + s].
 __global__ __launch_bounds__(256) void pack_wino4_kernel(const float *__restrict__ w, int Cout, int Cin, float *__restrict__ packed,
                                                          int64_t total) {
-    const double G[6][3] = {{0.25, 0.0, 0.0},          {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                            {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+    const double G[6][3] = {{0.5, 0.0, 0.0},           {1.0 / 6, 1.0 / 6, 1.0 / 6},     {1.0 / 6, -1.0 / 6, 1.0 / 6},
+                            {16.0 / 15, 8.0 / 15, 4.0 / 15}, {1.0 / 30, -1.0 / 15, 2.0 / 15}, {0.0, 0.0, 0.5}};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         int64_t r = i;
         const int idx = r % 4;  r /= 4;

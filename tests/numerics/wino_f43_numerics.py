@@ -59,10 +59,32 @@ def check_transform(AT, G, BT, m, r=3):
     assert np.allclose(y, ref, atol=1e-10), (y, ref)
 
 
+def integer_bt(AT, G, BT):
+    """Move each row's normalisation from B^T into G so that B^T has small integer entries (what a kernel would use: the input
+    transform is then exact multiplications by 2, 3, 4, 5 and additions; G g G^T is computed offline in double precision)."""
+    from fractions import Fraction
+    BT2, G2 = BT.copy(), G.copy()
+    for i in range(len(BT)):
+        fr = [Fraction(float(v)).limit_denominator(1000) for v in BT[i]]
+        den = 1
+        for f in fr:
+            den = den * f.denominator // np.gcd(den, f.denominator)
+        ints = [int(f * den) for f in fr]
+        g = 0
+        for v in ints:
+            g = np.gcd(g, abs(v))
+        scale = Fraction(den, max(int(g), 1))
+        BT2[i] = [float(f * scale) for f in fr]
+        G2[i] = G[i] / float(scale)
+    return AT, G2, BT2
+
+
 class WinoConv(object):
-    def __init__(self, m, points):
+    def __init__(self, m, points, integer=False):
         self.m = m
         AT, G, BT = cook_toom(points, m)
+        if integer:
+            AT, G, BT = integer_bt(AT, G, BT)
         check_transform(AT, G, BT, m)
         self.AT64, self.G64, self.BT64 = AT, G, BT
         self.AT = torch.from_numpy(AT).float()
@@ -139,6 +161,8 @@ def main():
                 ('F(4x4,3x3) {0,1,-1,2,-2}', WinoConv(4, [0, 1, -1, 2, -2])),
                 ('F(4x4,3x3) {0,1,-1,1/2,-1/2}', WinoConv(4, [0, 1, -1, 0.5, -0.5])),
                 ('F(4x4,3x3) {0,1,-1,1/2,-2}', WinoConv(4, [0, 1, -1, 0.5, -2])),
+                ('F(4x4,3x3) {0,1,-1,2,-2} integer B^T (the kernel)', WinoConv(4, [0, 1, -1, 2, -2], integer=True)),
+                ('F(4x4,3x3) {0,1,-1,1/2,-2} integer B^T', WinoConv(4, [0, 1, -1, 0.5, -2], integer=True)),
                 ('F(3x3,3x3) {0,1,-1,2}', WinoConv(3, [0, 1, -1, 2])),
                 ('F(3x3,3x3) {0,1,-1,1/2}', WinoConv(3, [0, 1, -1, 0.5]))]
     img = synthetic.make_image(H, W, 0, 'natural').unsqueeze(0).float()
