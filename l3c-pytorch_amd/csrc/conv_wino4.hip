@@ -246,21 +246,50 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
 #pragma unroll
             for (int i = 0; i < 5; ++i) L[col & 1][i] = src[(i * PW + col) * PSR];
         };
-        auto tr_col = [&](int col) {
+        // (the transform is dealt out between the MFMAs in slices of 4..8 instructions: a gap of 32 matrix-pipe cycles has room for ~7)
+        auto tr_col_a = [&](int col) {
             const float(&l)[5] = L[col & 1];
             if constexpr (TH == 0) {   // xi = 0, 1, 2 from raw rows 0 .. 4 (l[i] = row i)
                 T[0][col] = __builtin_fmaf(2.0f, l[0] + l[4], __builtin_fmaf(3.0f, l[3] - l[1], -4.0f * l[2]));
-                T[1][col] = __builtin_fmaf(2.0f, l[4], __builtin_fmaf(5.0f, l[3], __builtin_fmaf(-2.0f, l[1], l[2])));
-                T[2][col] = __builtin_fmaf(-2.0f, l[4], __builtin_fmaf(-2.0f, l[1], __builtin_fmaf(5.0f, l[2], -l[3])));
             } else {                   // xi = 3, 4, 5 from raw rows 1 .. 5 (l[i] = row 1 + i)
                 const float pp_ = l[0] - l[2], qq_ = l[1] - l[3];
                 T[0][col] = __builtin_fmaf(2.0f, pp_, qq_);
                 T[1][col] = __builtin_fmaf(-2.0f, qq_, pp_);
+            }
+        };
+        auto tr_col_b = [&](int col) {
+            const float(&l)[5] = L[col & 1];
+            if constexpr (TH == 0) {
+                T[1][col] = __builtin_fmaf(2.0f, l[4], __builtin_fmaf(5.0f, l[3], __builtin_fmaf(-2.0f, l[1], l[2])));
+                T[2][col] = __builtin_fmaf(-2.0f, l[4], __builtin_fmaf(-2.0f, l[1], __builtin_fmaf(5.0f, l[2], -l[3])));
+            } else {
                 T[2][col] = __builtin_fmaf(2.0f, l[0] + l[4], __builtin_fmaf(3.0f, l[3] - l[1], -4.0f * l[2]));
             }
         };
+        auto tr_col = [&](int col) {
+            tr_col_a(col);
+            tr_col_b(col);
+        };
         float R[6];
-        auto tr_row = [&](int k) { bt6(T[k], R); };
+        auto tr_row_part = [&](int k, int part) {   // row k through B^T in three slices (== bt6)
+            const float(&w)[6] = T[k];
+            if (part == 0) {
+                R[0] = __builtin_fmaf(2.0f, w[0] + w[4], __builtin_fmaf(3.0f, w[3] - w[1], -4.0f * w[2]));
+                R[1] = __builtin_fmaf(2.0f, w[4], __builtin_fmaf(5.0f, w[3], __builtin_fmaf(-2.0f, w[1], w[2])));
+            } else if (part == 1) {
+                R[2] = __builtin_fmaf(-2.0f, w[4], __builtin_fmaf(-2.0f, w[1], __builtin_fmaf(5.0f, w[2], -w[3])));
+                const float p_ = w[1] - w[3], q_ = w[2] - w[4];
+                R[3] = __builtin_fmaf(2.0f, p_, q_);
+                R[4] = __builtin_fmaf(-2.0f, q_, p_);
+            } else {
+                R[5] = __builtin_fmaf(2.0f, w[1] + w[5], __builtin_fmaf(3.0f, w[4] - w[2], -4.0f * w[3]));
+            }
+        };
+        auto tr_row = [&](int k) {
+            tr_row_part(k, 0);
+            tr_row_part(k, 1);
+            tr_row_part(k, 2);
+        };
         auto tr_write = [&](float *dst, int k) {   // row xi = 3 TH + k: positions (xi, 0..5) = pairs 3 xi .. 3 xi + 2
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -348,18 +377,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 L3C_W4_MFMA(2 * pp, A[0], Bv[0], true)
                 if (TR && pp >= 7 && pp <= 12) tr_load(r_src, pp - 7);        // one patch column per pair, pairs 7..12 (the burst's registers
                                                                               // free up as its pairs 3..9 are consumed)
-                if (TR && pp >= 13 && pp <= 15) tr_row(pp - 13);
+                if (TR && pp >= 13 && pp <= 15) tr_row_part(pp - 13, 0);
                 if (ST && pp == 16) store_piece(r_dst, 0, stage[0]);
                 if (ST && pp == 16) store_piece(r_dst, 1, stage[1]);
                 L3C_W4_MFMA(2 * pp + 1, A[2], Bv[2], true)
+                if (TR && pp >= 7 && pp <= 12) tr_col_a(pp - 7);
+                if (TR && pp >= 13 && pp <= 15) tr_row_part(pp - 13, 1);
                 if (ST && pp == 16) store_piece(r_dst, 2, stage[2]);
                 if (LB && !LAST && pp == 15) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) b_burst[k] = fetch_b(cc_b, 3 + k);
                 }
                 L3C_W4_MFMA(2 * pp, A[1], Bv[1], false)
-                if (TR && pp >= 7 && pp <= 12) tr_col(pp - 7);
-                if (TR && pp >= 13 && pp <= 15) tr_write(v_next, pp - 13);
+                if (TR && pp >= 7 && pp <= 12) tr_col_b(pp - 7);
+                if (TR && pp >= 13 && pp <= 15) {
+                    tr_row_part(pp - 13, 2);
+                    tr_write(v_next, pp - 13);
+                }
                 L3C_W4_MFMA(2 * pp + 1, A[3], Bv[3], false)
                 // (the rings are reloaded behind the pair's last MFMA: A and Bv are references into them)
                 if (pp < NPP - 2) a_ring[pp & 1] = *reinterpret_cast<const f32x4 *>(a_cur + (pp + 2) * VPP);
