@@ -86,6 +86,7 @@ class EncodedBatch(object):
         self.scales = []                     # (C, H, W, out uint8 (B*C, stride), nbytes int32 (B*C,))
         self.pending = []                    # (C, H, W, intervals) of prepare_batch, consumed by Bitcoding.code
         self.done = []                       # events on the coder streams; wait() orders the current stream after them
+        self.coder_stream = None             # the side stream of the last `code` call (the natural place for the D2H of the files)
 
     def wait(self):
         """Make the current stream wait for the range-coder launches (they run on side streams)."""
@@ -322,6 +323,7 @@ class Bitcoding(object):
         for enc in batches:
             enc.pending = []
             enc.done.append(done)
+            enc.coder_stream = side
         return batches
 
     def encode_batch(self, imgs, out=None):
@@ -333,7 +335,7 @@ class Bitcoding(object):
     N_FORWARD_STREAMS = 3     # used when the HIP runtime was given >= 8 hardware queues, see encode_many
     N_CODER_GROUPS = 4
 
-    def encode_many(self, batches):
+    def encode_many(self, batches, upload=None, on_group=None, n_groups=None, weights=None):
         """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries -- images of different sizes
         cannot share a batch).  -> list of EncodedBatch, in the order given.
         Small batches leave most of the machine idle (one 768x512 image is 192 tiles at the first scale, 12 at the
@@ -344,11 +346,19 @@ class Bitcoding(object):
             [measured: 64 images of 36 shapes end to end: 42 MPix/s on one stream, 38-43 on three with 4 queues, 52 with 8];
           * the range coder is launched N_CODER_GROUPS times (one grouped launch per quarter of the set, on the side
             streams), so that the long chains of the early, large images overlap the later forward passes and only the
-            short chains of the smallest images are left at the end."""
+            short chains of the smallest images are left at the end.
+        Host pipelining (helpers/dataset_codec.encode_set): `upload(entry)` turns an entry of `batches` into its device tensor
+        right before that forward pass is enqueued, under the forward stream (staging + H2D of batch k+1 then overlap the GPU's
+        work on batch k; `weights[i]` = the entry's pixel count, for the largest-first order); `on_group(list of (index,
+        EncodedBatch))` is called for a coder group as soon as its launch has completed (polled after every enqueued pass; the
+        rest at the end), under the side stream that coded it -- the D2H and the host's slicing of finished files overlap the
+        later groups' forward passes."""
         if not batches:
             return []
         self.blueprint.net._prepare()                  # pack the weights before forking streams
-        order = sorted(range(len(batches)), key=lambda i: -batches[i].shape[0] * batches[i].shape[2] * batches[i].shape[3])
+        if weights is None:
+            weights = [b.shape[0] * b.shape[2] * b.shape[3] for b in batches]
+        order = sorted(range(len(batches)), key=lambda i: -weights[i])
         main = torch.cuda.current_stream()
         if int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) >= 8:
             if getattr(self, '_fwd_streams', None) is None:
@@ -361,25 +371,41 @@ class Bitcoding(object):
         for st in fwd:
             if st is not main:
                 st.wait_event(start)
-        per_group = -(-len(order) // self.N_CODER_GROUPS)
+        per_group = -(-len(order) // (n_groups or self.N_CODER_GROUPS))
         result = [None] * len(batches)
-        pending = []
+        pending, coded = [], []
+
+        def collect_finished(block):
+            # oldest group first; without `block` only groups whose coder launch has COMPLETED (the host must never sit waiting for a
+            # latency-bound coder launch while the forward streams run dry)
+            while coded and (block or result[coded[0][0]].done[-1].query()):
+                self._collect(coded.pop(0), result, on_group)
+
         for n, i in enumerate(order):
             st = fwd[n % len(fwd)]
             with torch.cuda.stream(st):
-                x = batches[i]
+                x = batches[i] if upload is None else upload(batches[i])
                 if x.is_cuda:
                     x.record_stream(st)
                 result[i] = self.prepare_batch(x)
                 ev = torch.cuda.Event()
                 ev.record(st)
-            pending.append((result[i], ev))
+            pending.append((i, ev))
             if len(pending) == per_group or n == len(order) - 1:
                 for _, ev in pending:
                     main.wait_event(ev)            # `code` orders its side stream after the current stream
-                self.code([enc for enc, _ in pending])
+                self.code([result[k] for k, _ in pending])
+                if on_group is not None:
+                    coded.append([k for k, _ in pending])
                 pending = []
+            collect_finished(False)
+        collect_finished(True)
         return result
+
+    @staticmethod
+    def _collect(indices, result, on_group):
+        with torch.cuda.stream(result[indices[0]].coder_stream):
+            on_group([(k, result[k]) for k in indices])
 
     def decode_batch(self, files):
         """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU,

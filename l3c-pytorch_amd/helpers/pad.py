@@ -14,13 +14,18 @@ def _split(total):
     return first, total - first
 
 
+def padding_for(h, w, fac):
+    """(left, right, top, bottom) that `pad` would apply to an h x w image, (0, 0, 0, 0) if none."""
+    top, bottom = _split((-h) % fac)
+    left, right = _split((-w) % fac)
+    return (left, right, top, bottom)
+
+
 def pad(img, fac, mode='replicate'):
     _, _, h, w = img.shape
-    need_h, need_w = (-h) % fac, (-w) % fac
-    if not need_h and not need_w:
+    left, right, top, bottom = padding_for(h, w, fac)
+    if not (left or right or top or bottom):
         return img, _identity
-    top, bottom = _split(need_h)
-    left, right = _split(need_w)
     assert (h + top + bottom) % fac == 0 and (w + left + right) % fac == 0
     padding_tuple = (left, right, top, bottom)
     return F.pad(img, padding_tuple, mode), padding_tuple

@@ -73,3 +73,32 @@ def test_encode_set_files_match_the_oracle_image_by_image(l3c_checkpoint, calibr
             # implementations of P never guarantee identical tables), so only the header is asserted
             print('oracle decode of the HIP file: {} wrong sub-pixels of {}'.format(wrong, x.numel()))
             assert pt_o == pt
+
+
+def test_encode_set_pipeline_equals_per_image_encodes(l3c_checkpoint):
+    """The pipelined host path (page-locked staging, device-side zero padding, per-group collection) against the plain one: every file
+    must be BYTE-IDENTICAL to `encode_batch(pad(img))` of that image alone.  Three raw shapes share the padded shape 512x768 (one
+    forward pass: rows padded, columns padded, nothing padded), one shape needs both paddings, one chunk is cut by max_batch."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
+    from l3c_pytorch_amd.helpers import dataset_codec, pad, synthetic
+    cfg, sd = l3c_checkpoint(True)
+    bp = MultiscaleBlueprint(cfg)
+    bp.net.load_state_dict(sd, strict=True)
+    bp.set_eval()
+    bc = Bitcoding(bp)
+    shapes = [(510, 768), (512, 766), (512, 768), (509, 765), (512, 768), (200, 264), (200, 264), (200, 264), (197, 259)]
+    imgs = {i: synthetic.make_image(h, w, 40 + i, 'natural') for i, (h, w) in enumerate(shapes)}
+    order = list(range(len(shapes)))
+    for n_groups in (8, 2):
+        files, n_shapes, n_fwd = dataset_codec.encode_set(bc, imgs, order, max_batch=4, n_groups=n_groups)
+        assert n_shapes == 2 and n_fwd == 2 + 1            # 5 images of 512x768 at max_batch 4 -> 2 passes; 4 of 200x264 -> 1
+        assert sorted(files) == order
+        for i in order:
+            x, pt = pad.pad(imgs[i].unsqueeze(0), 8, mode='constant')
+            pt = pt if isinstance(pt, tuple) else (0, 0, 0, 0)
+            alone = bc.encode_batch(x.cuda()).to_bytes([pt])[0]
+            assert files[i] == alone, (i, len(files[i]), len(alone))
+    # and a second call reuses the staging ring
+    again, _, _ = dataset_codec.encode_set(bc, imgs, order[::-1], max_batch=16)
+    assert all(again[i] == files[i] for i in order)
