@@ -332,7 +332,7 @@ class Bitcoding(object):
         `out`: a network output for `imgs` computed earlier (avoids a second forward)."""
         return self.code([self.prepare_batch(imgs, out)])[0]
 
-    N_FORWARD_STREAMS = 3     # used when the HIP runtime was given >= 8 hardware queues, see encode_many
+    N_FORWARD_STREAMS = int(os.environ.get('L3C_FORWARD_STREAMS', '3'))     # used when the HIP runtime was given >= 8 hardware queues, see encode_many
     N_CODER_GROUPS = 4
 
     def encode_many(self, batches, upload=None, on_group=None, n_groups=None, weights=None):

@@ -331,7 +331,7 @@ class MultiscaleTester(object):
             chunk, pending[shape] = pending[shape][:self.max_batch], pending[shape][self.max_batch:]
             if not pending[shape]:
                 del pending[shape]
-            batch = torch.cat([c[2] for c in chunk], dim=0).to('cuda', torch.float32)
+            batch = torch.cat([c[2] for c in chunk], dim=0).cuda().float()      # bytes over PCIe, widened on the device
             out = self.blueprint.forward(batch, self.recursive)
             for (i, n_sub, _), b in zip(chunk, self.per_image_bpsp(out, [c[1] for c in chunk])):
                 per_img[i][0].add(float(b), n_sub)

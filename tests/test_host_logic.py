@@ -210,3 +210,23 @@ def test_saturated_sigmoid_shortcuts_are_exact_in_fp32():
         e = np.exp(-lo)                                   # fp32 overflow -> inf
         assert np.all(np.isinf(e)) and np.all(np.float32(1.0) / (np.float32(1.0) + e) == 0.0)
     assert np.exp(np.float64(89.0)) > float(np.finfo(np.float32).max) * 1.3                       # e^89 overflows fp32 with margin
+
+
+def test_image_set_plan_matches_host_padding():
+    """dataset_codec.plan_set (config 4's host plan: no pixel touched) against pad.pad: the padded shape and the padding tuple of every
+    image are what the reference's centre padding gives (helpers/pad.py:23-59); chunks hold at most max_batch images of ONE padded shape
+    and together cover the set exactly once."""
+    from l3c_pytorch_amd.helpers import dataset_codec, pad
+    sizes = dataset_codec.draw_sizes(120, seed=3) + [(510, 768), (512, 766), (509, 765), (512, 768)]
+    order = list(range(len(sizes)))
+    chunks, padded, pads, n_shapes = dataset_codec.plan_set(dict(enumerate(sizes)), order, 4, 8)
+    assert sorted(i for c in chunks for i in c) == order
+    assert n_shapes == len(set(padded)) and all(1 <= len(c) <= 4 for c in chunks)
+    for c, shape in zip(chunks, padded):
+        for i in c:
+            h, w = sizes[i]
+            x, pt = pad.pad(torch.zeros(1, 3, h, w, dtype=torch.uint8), 8, mode='constant')
+            assert tuple(x.shape[-2:]) == shape
+            assert (pt if isinstance(pt, tuple) else (0, 0, 0, 0)) == pads[i]
+    # images of different raw shapes belong to one group when their padded shapes agree
+    assert {shape for c, shape in zip(chunks, padded) for i in c if i >= 120} == {(512, 768)}

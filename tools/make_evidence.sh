@@ -3,6 +3,7 @@
 #
 #     /usr/local/graft/bin/gpurun --timeout 2400 -- tools/make_evidence.sh      # on the GPU box: writes gpurun_out/evidence/
 #     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r03_*
+#     /usr/local/graft/bin/gpurun --timeout 900 -- tools/make_evidence.sh --bench-only   # the bench lines only (after host-side changes)
 #
 # Steps on the GPU box: (1) the default bench line (after the PMC passes, so that it carries their table); (2) the 768x512 parity suite (tests/test_gpu_headline.py writes the measured
 # errors); (3) rocprofv3 --kernel-trace --stats over the same bench command; (4) three separate rocprofv3 --pmc passes (FETCH_SIZE /
@@ -27,6 +28,16 @@ fi
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
 E=$PWD/gpurun_out/evidence
+if [ "$1" == "--bench-only" ]; then
+    # the three bench lines only (host-side changes: the kernel sources, hence the committed PMC table and kernel statistics, are unchanged --
+    # bench.py checks that by the source stamp); merged into the existing gpurun_out/evidence/ by --collect
+    mkdir -p "$E"
+    timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err
+    timeout 900 python bench.py --config dataset > $E/bench_dataset.json 2> $E/bench_dataset.err
+    timeout 600 python bench.py --config large > $E/bench_large.json 2> $E/bench_large.err
+    tail -c 1200 $E/bench_default.json; cat $E/bench_dataset.json | cut -c1-300
+    exit 0
+fi
 rm -rf "$E"; mkdir -p "$E"
 LIGHT="--no-cpu-baseline --no-parity --no-extra-legs"
 timeout 900 python -m pytest tests/test_gpu_headline.py -q > $E/pytest_headline.log 2>&1
