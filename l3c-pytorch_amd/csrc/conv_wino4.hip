@@ -121,10 +121,34 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 
 // Development probes (csrc/build.py --variant NAME "-DL3C_W4_PROBE=N"; results are WRONG, only the time means something): bit 0 no
 // patch fetch, 1 no input transform, 2 no weight loads inside the loop, 3 no chunk barrier, 4 no output transform / stores (one
-// store per tile keeps the accumulators alive), 5 no patch stores to LDS.  Never defined in the product build.
+// store per tile keeps the accumulators alive), 5 no patch stores to LDS, 6 no MFMA (one v_add in its place: the data-movement
+// skeleton alone), 7 all weight loads from the same 4 KB (L1 hits: the instruction stream without the L2 traffic), 8 the input addressed
+// as [C/8][H][W][8], 9 every block fetches the same patch pixels (the fetch instructions without their HBM / L2 latency).  Never defined in the product build.
 #ifndef L3C_W4_PROBE
 #define L3C_W4_PROBE 0
 #endif
+// Schedule knob (A/B builds): TR_LEAD = pairs between the LDS reads of a raw patch column and the arithmetic that consumes them (0: the
+// s_waitcnt lgkmcnt(0) in front of the column arithmetic sits one MFMA behind its ds_reads; 1: a whole pair, the waits become
+// lgkmcnt(4..5)).  [measured, 64->64 at 256x384x32: 0.768 / 0.766 ms -- the LDS latency was not what idles the matrix pipe; likewise
+// s_setprio 1 inside the chunk loop and 0 in the output transform, or the other way round: 0.758 / 0.766 ms, within the noise, not kept]
+#ifndef L3C_W4_TR_LEAD
+#define L3C_W4_TR_LEAD 1
+#endif
+// Depth of the weight ring = its lookahead in position pairs (4 or 6; a slot is a register quad).
+#ifndef L3C_W4_RING
+#define L3C_W4_RING 6
+#endif
+// Pair at which a chunk stores the staged patch to LDS and fetches the next one (16: right behind the weight burst, see the chunk lambda).
+// Residual quads in flight in the output transform (round k's residual is loaded RES_RING - 1 rounds before its store).
+#ifndef L3C_W4_RES_RING
+#define L3C_W4_RES_RING 4
+#endif
+#ifndef L3C_W4_FETCH_PP
+#define L3C_W4_FETCH_PP 16
+#endif
+static_assert(L3C_W4_RING == 4 || L3C_W4_RING == 6, "ring depth");
+// slot of pair q (numbered on into the next chunk) in a chunk of buffer parity par: 18 pairs per chunk = 2 mod 4, 0 mod 6
+__device__ __forceinline__ constexpr int ring_slot(int q, int par) { return L3C_W4_RING == 4 ? ((q + 2 * par) & 3) : q % 6; }
 
 template <bool RELU, bool RES, bool SHUFFLE>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p) {
@@ -162,7 +186,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     // input's channels, phase 1: ...), the weights are those of a convolution with 4 Cin input channels (phase-major)
     const int istep = p.poly ? 2 : dil;
     const int ncp = p.poly_ncp > 0 ? p.poly_ncp : n_cc, n_phase = p.poly_ncp > 0 ? 4 : 1;
-    const int pf_row_b = 6 * istep * p.W * p.in_cstride * 4;                   // six patch rows on, in bytes
+    constexpr bool PLANAR_PROBE = (L3C_W4_PROBE & 256) != 0;   // timing only: input addressed as [C/8][H][W][8] (a chunk's pieces contiguous)
+    const int in_pix_b = PLANAR_PROBE ? CK * 4 : p.in_cstride * 4;
+    const int pf_row_b = 6 * istep * p.W * in_pix_b;                           // six patch rows on, in bytes
     const int pf_lds = (pf_r0 * PW + (pf_j >> 1)) * PSR + (pf_j & 1) * 4;       // LDS position of piece 0 (floats); + k * 6 * PW * PSR
     int patch_off;
     auto fresh_tid = [&]() {   // the thread index, recomputed where it is used rarely (kept out of the registers the MFMA loop holds)
@@ -177,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         const int iy = ipy + istep * (sy0 - 1 + r0), ix = ipx + istep * ((tx_first + t) * OT - 1 + (j >> 1));
         const bool ok = r0 < 6 && ix >= 0 && ix < p.W;
         // (iy may be negative: the offset wraps to a huge unsigned value and the load returns zero; iy + 6 k then comes back in range)
-        patch_off = ok ? ((iy * p.W + ix) * p.in_cstride + (j & 1) * 4) * 4 : (int)0xC0000000;   // (+ 2 rows: still beyond 2 GB)
+        patch_off = ok ? (iy * p.W + ix) * in_pix_b + (j & 1) * 16 : (int)0xC0000000;   // (+ 2 rows: still beyond 2 GB)
+        if constexpr (L3C_W4_PROBE & 512) patch_off = (r0 * PW + (j >> 1)) * in_pix_b + (j & 1) * 16;   // timing only: every block fetches the same pixels (cache hits)
     };
     int pf_tile = 0, pf_ph = 0, pf_cc = 0;   // the prefetch pointer: (tile, phase, chunk of the phase) of the next patch to fetch
     auto pf_advance = [&]() {
@@ -199,6 +226,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     f32x4 stage[NIT];
     auto fetch_piece = [&](int it) {
         if constexpr (L3C_W4_PROBE & 1) return;
+        if constexpr (PLANAR_PROBE) {
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(p.in + (size_t)b * p.H * p.W * p.in_cstride + (size_t)pf_cc * p.H * p.W * CK), 0, p.H * p.W * CK * 4, 0x00020000);
+            stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, patch_off + it * pf_row_b, 0, 0));
+            return;
+        }
         stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off + it * pf_row_b, pf_cc * CK * 4, 0));
     };
     auto store_piece = [&](float *dst, int it, const f32x4 &v) {
@@ -209,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const auto u_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.u + (size_t)chunk_o * n_cc * U_CHUNK_FLOATS), 0,
                                                           n_cc * U_CHUNK_FLOATS * 4, 0x00020000);
     const int u_lane = (wave * 64 + lane) * 16;
-    f32x4 b_ring[4];
+    f32x4 b_ring[L3C_W4_RING];
     auto fetch_b = [&](int cc, int pp) {
+        if constexpr (L3C_W4_PROBE & 128) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (pp & 3) * (4 * 64 * 16), 0));
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (cc * NPP + pp) * (4 * 64 * 16), 0));
     };
 
@@ -313,7 +347,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             for (int it = 0; it < NIT; ++it) fetch_piece(it);
             pf_advance();
 #pragma unroll
-            for (int q = 0; q < 4; ++q) b_ring[q] = fetch_b(0, q);
+            for (int q = 0; q < L3C_W4_RING; ++q) b_ring[q] = fetch_b(0, q);
 #pragma unroll
             for (int it = 0; it < NIT; ++it) store_piece(lds + RAW_OFF0, it, first[0][it]);
 #pragma unroll
@@ -362,28 +396,30 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             constexpr bool TR = !(L3C_W4_PROBE & 2), ST = !(L3C_W4_PROBE & 32), LB = !(L3C_W4_PROBE & 4);
 #define L3C_W4_MFMA(Q, A, B, ZERO)                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (FIRST && (ZERO) && (Q) != 7) ? zero4 : acc[Q], 0, 0, 0); \
+    if constexpr (L3C_W4_PROBE & 64) { asm volatile("v_add_f32 %0, %1, %2" : "+v"(acc[Q][0]) : "v"(A), "v"(B)); }          \
+    else acc[Q] = __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (FIRST && (ZERO) && (Q) != 7) ? zero4 : acc[Q], 0, 0, 0); \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < NPP; ++pp) {
                 const f32x4 &A = a_ring[pp & 1];
                 const bool from_burst = !FIRST && pp >= 3 && pp <= 9;
-                const f32x4 &Bv = from_burst ? b_burst[pp >= 3 && pp <= 9 ? pp - 3 : 0] : b_ring[(pp + 2 * par) & 3];
+                const f32x4 &Bv = from_burst ? b_burst[pp >= 3 && pp <= 9 ? pp - 3 : 0] : b_ring[ring_slot(pp, par)];
                 if (pp == NPP - 1) {
                     // everything chunk g + 1 needs from this wave is issued: V[par ^ 1] written, patch g + 2 stored
                     if constexpr (!(L3C_W4_PROBE & 8)) __syncthreads();
                     a_ring[0] = *reinterpret_cast<const f32x4 *>(a_nxt);
                 }
                 L3C_W4_MFMA(2 * pp, A[0], Bv[0], true)
-                if (TR && pp >= 7 && pp <= 12) tr_load(r_src, pp - 7);        // one patch column per pair, pairs 7..12 (the burst's registers
-                                                                              // free up as its pairs 3..9 are consumed)
+                // one patch column per pair, arithmetic in pairs 7..12 (the burst's registers free up as its pairs 3..9 are consumed), its
+                // five LDS reads TR_LEAD pairs earlier (two columns in flight: L[col & 1])
+                if (TR && pp >= 7 - L3C_W4_TR_LEAD && pp <= 12 - L3C_W4_TR_LEAD) tr_load(r_src, pp - 7 + L3C_W4_TR_LEAD);
                 if (TR && pp >= 13 && pp <= 15) tr_row_part(pp - 13, 0);
-                if (ST && pp == 16) store_piece(r_dst, 0, stage[0]);
-                if (ST && pp == 16) store_piece(r_dst, 1, stage[1]);
+                if (ST && pp == L3C_W4_FETCH_PP) store_piece(r_dst, 0, stage[0]);
+                if (ST && pp == L3C_W4_FETCH_PP) store_piece(r_dst, 1, stage[1]);
                 L3C_W4_MFMA(2 * pp + 1, A[2], Bv[2], true)
                 if (TR && pp >= 7 && pp <= 12) tr_col_a(pp - 7);
                 if (TR && pp >= 13 && pp <= 15) tr_row_part(pp - 13, 1);
-                if (ST && pp == 16) store_piece(r_dst, 2, stage[2]);
+                if (ST && pp == L3C_W4_FETCH_PP) store_piece(r_dst, 2, stage[2]);
                 if (LB && !LAST && pp == 15) {
 #pragma unroll
                     for (int k = 0; k < 3; ++k) b_burst[k] = fetch_b(cc_b, 3 + k);
@@ -400,15 +436,17 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 if (pp == NPP - 1) a_ring[1] = *reinterpret_cast<const f32x4 *>(a_nxt + VPP);
                 // the ring: pair pp + 4 -- of this chunk, or (numbered on) of the next one, whose pairs 3..9 come from the burst
                 if constexpr (LB) {
-                    const int nxt = pp + 4;
+                    const int nxt = pp + L3C_W4_RING;
                     const bool ring_load = nxt < NPP ? (FIRST || nxt >= 10) : (LAST || nxt - NPP <= 2);
-                    if (ring_load) b_ring[(nxt + 2 * par) & 3] = nxt < NPP ? fetch_b(cc, nxt) : fetch_b(cc_b, nxt - NPP);
+                    if (ring_load) b_ring[ring_slot(nxt, par)] = nxt < NPP ? fetch_b(cc, nxt) : fetch_b(cc_b, nxt - NPP);
                 }
                 if (pp == 16) {
                     if (LB && !LAST) {
 #pragma unroll
                         for (int k = 3; k < 7; ++k) b_burst[k] = fetch_b(cc_b, 3 + k);
                     }
+                }
+                if (pp == L3C_W4_FETCH_PP) {
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) fetch_piece(it);   // patch of chunk g + 3, behind the burst
                     pf_advance();
@@ -459,19 +497,23 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 const bool ok = lane_ok && oy_l + dil * i < p.Ho && ox_l + dil * 4 * r < p.Wo;
                 return ok ? base : OOB;
             };
-            f32x4 resv[3];
+            f32x4 resv[L3C_W4_RES_RING];
             auto res_load = [&](int k) {   // round k = r * 4 + i
                 if constexpr (RES)
-                    resv[k % 3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                    resv[k % L3C_W4_RES_RING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                 r_rsrc, lane_off(r_lane, k >> 2, k & 3), (k & 3) * rrow_b + (sx0 + 4 * (k >> 2)) * rcol_b, 0));
             };
             auto flush = [&](int k) {      // round k: window -> registers -> memory
                 f32x4 v = *reinterpret_cast<const f32x4 *>(w_src + (k & 1) * WIN_FLOATS);
-                if constexpr (RELU) {
+                if constexpr (RELU) {   // (fmaxf would first canonicalise the value read from LDS: a second v_max per element)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.0f);
+                    for (int e = 0; e < 4; ++e) {
+                        float m;
+                        asm("v_max_f32 %0, 0, %1" : "=v"(m) : "v"(v[e]));
+                        v[e] = m;
+                    }
                 }
-                if constexpr (RES) v = v + resv[k % 3];
+                if constexpr (RES) v = v + resv[k % L3C_W4_RES_RING];
                 const int vo = lane_off(o_lane, k >> 2, k & 3), so = (k & 3) * row_b + (sx0 + 4 * (k >> 2)) * col_b;
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
@@ -490,8 +532,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                                                        o_rsrc, lane_off(o_lane, 0, 0), sx0 * col_b, 0);
                 continue;
             }
-            res_load(0);
-            res_load(1);
+#pragma unroll
+            for (int k = 0; k + 1 < L3C_W4_RES_RING; ++k) res_load(k);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float tcol[4][6];   // t[i][nu] = sum_xi A^T[i][xi] M[xi][nu]
@@ -514,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     if (k >= 1) flush(k - 1);
-                    if (k + 2 < 16) res_load(k + 2);   // (into the register quad flush(k - 1) has just released)
+                    if (k + L3C_W4_RES_RING - 1 < 16) res_load(k + L3C_W4_RES_RING - 1);   // (into the register quad flush(k - 1) has just released)
                 }
             }
             flush(15);
