@@ -143,6 +143,14 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 #ifndef L3C_W4_RES_RING
 #define L3C_W4_RES_RING 4
 #endif
+// Cache-policy bits of the output stores / the residual loads (A/B builds; [measured, 64->64 at 256x384x32, relu / residual variant:
+// 0 / 0: 0.743 / 0.858 ms; stores nt: 0.762 / 0.873; residual nt: 0.746 / 0.871; both: 0.761 / 0.889; stores sc0: 0.751 / 0.847] -- left at 0)
+#ifndef L3C_W4_OUT_AUX
+#define L3C_W4_OUT_AUX 0
+#endif
+#ifndef L3C_W4_RES_AUX
+#define L3C_W4_RES_AUX 0
+#endif
 #ifndef L3C_W4_FETCH_PP
 #define L3C_W4_FETCH_PP 16
 #endif
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             auto res_load = [&](int k) {   // round k = r * 4 + i
                 if constexpr (RES)
                     resv[k % L3C_W4_RES_RING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                                                r_rsrc, lane_off(r_lane, k >> 2, k & 3), (k & 3) * rrow_b + (sx0 + 4 * (k >> 2)) * rcol_b, 0));
+                                                                r_rsrc, lane_off(r_lane, k >> 2, k & 3), (k & 3) * rrow_b + (sx0 + 4 * (k >> 2)) * rcol_b, L3C_W4_RES_AUX));
             };
             auto flush = [&](int k) {      // round k: window -> registers -> memory
                 f32x4 v = *reinterpret_cast<const f32x4 *>(w_src + (k & 1) * WIN_FLOATS);
@@ -517,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 const int vo = lane_off(o_lane, k >> 2, k & 3), so = (k & 3) * row_b + (sx0 + 4 * (k >> 2)) * col_b;
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, v),
-                                                       o_rsrc, vo, so, 0);
+                                                       o_rsrc, vo, so, L3C_W4_OUT_AUX);
                 // gfx950: a VALU write to the data registers of a 16-byte buffer store with a REGISTER soffset, issued right behind
                 // it, overtakes the store's read of its last dwords, and the compiler inserts no wait states for this form
                 // (found with conv_wino.hip; tools/check_store_hazard.py scans the ISA at build time)
