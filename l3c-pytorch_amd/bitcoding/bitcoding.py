@@ -371,7 +371,14 @@ class Bitcoding(object):
         for st in fwd:
             if st is not main:
                 st.wait_event(start)
-        per_group = -(-len(order) // (n_groups or self.N_CODER_GROUPS))
+        # coder groups: n_groups equal ones, or cut points given as cumulative fractions of the passes (dataset_codec: halving groups, so
+        # that the last coder launch -- the one nothing overlaps -- covers only the smallest 1/16 of the set)
+        if isinstance(n_groups, (list, tuple)):
+            cuts = sorted({min(len(order), max(1, int(round(f * len(order))))) for f in n_groups} | {len(order)})
+        else:
+            per_group = -(-len(order) // (n_groups or self.N_CODER_GROUPS))
+            cuts = list(range(per_group, len(order), per_group)) + [len(order)]
+        cuts = set(cuts)
         result = [None] * len(batches)
         pending, coded = [], []
 
@@ -391,7 +398,7 @@ class Bitcoding(object):
                 ev = torch.cuda.Event()
                 ev.record(st)
             pending.append((i, ev))
-            if len(pending) == per_group or n == len(order) - 1:
+            if n + 1 in cuts:
                 for _, ev in pending:
                     main.wait_event(ev)            # `code` orders its side stream after the current stream
                 self.code([result[k] for k, _ in pending])

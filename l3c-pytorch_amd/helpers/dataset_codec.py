@@ -68,7 +68,7 @@ def plan_set(shapes, order, max_batch, fac):
     return chunks, padded, pads, len(groups)
 
 
-def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=8):
+def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None):
     """imgs: {index: uint8 (3,H,W) HOST tensor}; order: the indices to code.  -> ({index: `.l3c` bytes}, number of distinct
     padded shapes, number of forward passes).  `marks` (dict) receives host time stamps of the stages.
 
@@ -81,7 +81,10 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=8):
       * this happens right before the pass is enqueued (Bitcoding.encode_many's `upload` hook), so staging pass k+1 overlaps
         the GPU's work on pass k;
       * the files of coder group g are assembled on the device, copied back and cut into bytes objects while the GPU runs
-        the forward passes of group g+1 (`on_group` hook), on the side stream that coded them."""
+        the forward passes of group g+1 (`on_group` hook), on the side stream that coded them.  n_groups (default: one group per
+        ~13 passes, 2..8): nothing overlaps the last coder launch and its collection, and the first group holds the longest chains
+        [measured: 100 images (53 passes): 8 / 4 / 2 equal groups 104 / 120 / 108 MPix/s, halving groups (1/2, 1/4, ...) 99-102, a small
+        first and last group 105-108; 500 images (224 passes): 8 equal groups 143-148, 16 / 32: 125-147 / 110-113, halving 139-143]."""
     import time
     from ..bitcoding.bitcoding import EncodedBatch
 
@@ -139,6 +142,8 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=8):
         spent['collect files (sizes, assembly, D2H, slicing)'] += time.perf_counter() - t0
 
     weights = [len(c) * p[0] * p[1] for c, p in zip(chunks, padded)]
+    if n_groups is None:
+        n_groups = max(2, min(8, int(round(len(chunks) / 13.0))))
     bc.encode_many(list(range(len(chunks))), upload=upload, on_group=on_group, n_groups=n_groups, weights=weights)
     mark('staging + H2D + forward + coder + D2H + files (pipelined)')
     if marks is not None:

@@ -25,7 +25,7 @@ def main():
     ap.add_argument('--images', dest='n', type=int, default=64)
     ap.add_argument('--max-batch', type=int, default=16)
     ap.add_argument('--repeat', type=int, default=2, help='timed passes over the set (the first one also warms the allocator)')
-    ap.add_argument('--groups', type=int, default=8, help='coder launches (and file collections) per set')
+    ap.add_argument('--groups', type=int, default=0, help='equal coder groups per set (0: the halving groups of encode_set)')
     ap.add_argument('--no-probe', action='store_true')
     a = ap.parse_args()
     cfg = config_parser.parse_builtin('ms', 'cr')
@@ -54,7 +54,7 @@ def main():
     for _ in range(a.repeat):
         marks = {}
         t0 = time.perf_counter()
-        files, n_shapes, n_launches = dataset_codec.encode_set(bc, imgs, order, max_batch=a.max_batch, marks=marks, n_groups=a.groups)
+        files, n_shapes, n_launches = dataset_codec.encode_set(bc, imgs, order, max_batch=a.max_batch, marks=marks, **({'n_groups': a.groups} if a.groups else {}))
         dt = time.perf_counter() - t0
         report(a, sizes, files, n_shapes, n_launches, dt, t0, marks)
 
