@@ -47,6 +47,7 @@ import torch  # noqa: E402
 
 H, W = 512, 768
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
+HBM_PEAK_GBS = 8000.0               # same guide: HBM3E, 8 TB/s
 ALGO_FLOP_PER_PX = 1367796         # conv stack of the L3C forward, FLOP per image pixel
 RGB_SHARED_FLOP_PER_PX = 869168    # RGB Shared with auto_recurse 3
 
@@ -242,6 +243,13 @@ def roofline_leg(records, args, elapsed):
             'per_kernel': {k: {'algorithmic_tflops': round(v[0] / v[1] / 1e12, 1), 'share_of_step': round(v[1] / elapsed, 3),
                                'launches_per_step': v[2] // args.steps, 'algorithmic_gb_per_launch': round(v[3] / v[2] / 1e9, 3)}
                            for k, v in sorted(by.items())}}
+    # the other side of the roofline: since F(4x4,3x3) the kernel sits at the ridge -- its algorithmic HBM bytes at the
+    # HBM peak take about as long as its executed FLOPs at the MFMA peak, and the measured time is close to the SUM of the two
+    hbm_s, mfma_s = nbytes / n / (HBM_PEAK_GBS * 1e9), flops * executed / n / (FP32_MFMA_PEAK_TFLOPS * 1e12)
+    roof['hbm_side'] = {'algorithmic_gb_per_s': round(nbytes / secs / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': round(nbytes / secs / 1e9 / HBM_PEAK_GBS, 4),
+                        'launch_time_at_hbm_peak_us': round(hbm_s * 1e6, 1), 'launch_time_at_mfma_peak_us': round(mfma_s * 1e6, 1),
+                        'frac_of_the_larger_bound': round(max(hbm_s, mfma_s) / (secs / n), 4)}
     pmc, state = load_pmc_table()
     roof['pmc_table'] = {'file': PMC_TABLE, 'state': state, 'csrc_stamp': csrc_stamp()}
     if pmc and state == 'current' and pmc.get('batch') == args.batch:    # counters taken on OTHER kernel sources are not reported
