@@ -351,7 +351,8 @@ def run_headline(args, ranks):
     from l3c_pytorch_amd import _lib, ops
     B = args.batch
     # synthetic images (seed = global image index), resident in HBM before the timed region
-    imgs = torch.stack([synthetic.make_image(H, W, ranks.rank * B + i, 'natural') for i in range(B)]).to(ranks.device)
+    with single_thread():
+        imgs = torch.stack([synthetic.make_image(H, W, ranks.rank * B + i, 'natural') for i in range(B)]).to(ranks.device)
     imgs_f = imgs.float().contiguous()
     torch.cuda.synchronize()
     compute_stream = bc.compute_stream if bc.compute_stream is not None else torch.cuda.current_stream()
@@ -454,7 +455,8 @@ def run_dataset(args, ranks):
     from l3c_pytorch_amd.helpers import dataset_codec, pad, sharding
     sizes = dataset_codec.draw_sizes(args.images)
     mine = sharding.shard_indices(args.images, ranks.rank, ranks.world)
-    imgs = {i: synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural') for i in mine}     # host uint8
+    with single_thread():
+        imgs = {i: synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural') for i in mine}     # host uint8
 
     def step():
         return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch)
@@ -497,7 +499,8 @@ def run_large(args, ranks):
     shapes = [(2000, 3000), (1500, 2000)]
     batches, px, crops_of = [], 0, []
     for k, (h, w) in enumerate(shapes):
-        img = synthetic.make_image(h, w, 1000 + 2 * ranks.rank + k, 'natural').unsqueeze(0)
+        with single_thread():
+            img = synthetic.make_image(h, w, 1000 + 2 * ranks.rank + k, 'natural').unsqueeze(0)
         crops = list(auto_crop.iter_crops(img))             # unpatched threshold: H*W > 2000*1500 -> 2x2 crops
         crops_of.append(len(crops))
         padded = [pad.pad(c, fac, mode='constant')[0] for c in crops]
@@ -550,6 +553,19 @@ def run_stub(args, ranks):
         return None
     return contract(args, ranks, px * args.steps / 1e6 / elapsed, elapsed, data='stub (no GPU work)',
                     config={'workload': 'stub step: sleep 10 ms x (rank + 1)', 'items': 4 * ranks.world + 1})
+
+
+class single_thread(object):
+    """Synthetic images are made of small torch / numpy operations: on a 256-thread host torch's intra-op pool makes each of them
+    SLOWER (0.32 s per 768x512 image with 8 threads, 0.11 s with one [measured in the build container]) -- set-up time only, outside the
+    timed region, but it is most of the wall time of `--config dataset`."""
+
+    def __enter__(self):
+        self.saved = torch.get_num_threads()
+        torch.set_num_threads(1)
+
+    def __exit__(self, *exc):
+        torch.set_num_threads(self.saved)
 
 
 def spawn_ranks(args, argv):
