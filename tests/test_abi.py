@@ -133,3 +133,14 @@ def test_no_store_data_hazard_in_isa():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_store_hazard.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_mfma_kernels_stay_inside_their_register_budget():
+    """conv_wino4_kernel holds 144 accumulators per lane at two blocks per CU: every variant the network launches must fit 256 VGPRs
+    without scratch spills (the allocator once spilled 7 registers of the residual variant's epilogue); tools/check_registers.py reads the
+    code-object metadata of the ISA compiled with the product flags."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_registers.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'l3c-pytorch_amd', 'csrc')
 WINDOW = 2
 STORE = re.compile(r'^(buffer_store_dwordx[34])\s+(v\[\d+:\d+\]),\s*[^,]+,\s*s\[\d+:\d+\],\s*(\S+)')
-WRITERS = ('v_', 'ds_read', 'buffer_load', 'global_load', 'flat_load', 'scratch_load')
+# VALU writes only: a load into the store's data registers returns its data tens of cycles after the store has read them (conv_wino.hip,
+# compiled with the product flags, has `buffer_store_dwordx4 v[0:3] ... ; ds_read_b128 v[0:3]` pairs and is bit-exact in tests/test_gpu_conv.py)
+WRITERS = ('v_',)
 
 
 def regs(tok):
@@ -30,12 +32,24 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+def product_flags(src):
+    """The flags csrc/build.py compiles `src` with (the scan has to look at the ISA that ships: -fno-slp-vectorize changes the schedule)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('l3c_csrc_build', os.path.join(CSRC, 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return [f for f in mod.FLAGS if f not in ('-fPIC', '-Wall', '-Wno-unused-function')] + mod.SOURCE_FLAGS.get(os.path.basename(src), [])
+
+
+def compile_to_isa(src, out):
+    subprocess.check_call(['/opt/rocm/bin/hipcc'] + product_flags(src) + ['-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
+                                                                          '-o', out, src], cwd=os.path.dirname(out), stderr=subprocess.DEVNULL)
+
+
 def scan(src):
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, 'k.s')
-        subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
-                               '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only', '-o', out, src],
-                              cwd=tmp, stderr=subprocess.DEVNULL)
+        compile_to_isa(src, out)
         lines = [l.split(';')[0].strip() for l in open(out)]
     ins = [l for l in lines if l and not l.startswith('.') and not l.endswith(':')]
     hits = []
