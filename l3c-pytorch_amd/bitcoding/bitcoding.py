@@ -68,6 +68,17 @@ def _staging(nbytes):
     return buf[:nbytes]
 
 
+def coder_group_cuts(n_passes, n_groups):
+    """After which forward passes (1-based counts, ascending, the last one == n_passes) `encode_many` launches the range coder:
+    n_groups equal groups (int), or cut points given as cumulative fractions of the passes (list / tuple, e.g. (0.5, 0.75, 1.0))."""
+    if n_passes <= 0:
+        return []
+    if isinstance(n_groups, (list, tuple)):
+        return sorted({min(n_passes, max(1, int(round(f * n_passes)))) for f in n_groups} | {n_passes})
+    per_group = -(-n_passes // max(1, int(n_groups)))
+    return list(range(per_group, n_passes, per_group)) + [n_passes]
+
+
 def rgb_pipeline_schedule(n_chunks, C, D):
     """Steps of the chunk-pipelined RGB decode: step t handles chunk t - D c of channel c.  Returns a list (one entry per
     step) of lists of (channel, chunk).  Channel c's chunk j needs the symbols of the channels < c in chunk j: with D = 1
@@ -371,14 +382,7 @@ class Bitcoding(object):
         for st in fwd:
             if st is not main:
                 st.wait_event(start)
-        # coder groups: n_groups equal ones, or cut points given as cumulative fractions of the passes (dataset_codec: halving groups, so
-        # that the last coder launch -- the one nothing overlaps -- covers only the smallest 1/16 of the set)
-        if isinstance(n_groups, (list, tuple)):
-            cuts = sorted({min(len(order), max(1, int(round(f * len(order))))) for f in n_groups} | {len(order)})
-        else:
-            per_group = -(-len(order) // (n_groups or self.N_CODER_GROUPS))
-            cuts = list(range(per_group, len(order), per_group)) + [len(order)]
-        cuts = set(cuts)
+        cuts = set(coder_group_cuts(len(order), n_groups or self.N_CODER_GROUPS))
         result = [None] * len(batches)
         pending, coded = [], []
 

@@ -230,3 +230,19 @@ def test_image_set_plan_matches_host_padding():
             assert (pt if isinstance(pt, tuple) else (0, 0, 0, 0)) == pads[i]
     # images of different raw shapes belong to one group when their padded shapes agree
     assert {shape for c, shape in zip(chunks, padded) for i in c if i >= 120} == {(512, 768)}
+
+
+def test_coder_group_cuts():
+    """Bitcoding.encode_many launches the coder after these pass counts: equal groups, or cuts at given fractions; always ascending,
+    always ending with the last pass, never an empty group."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import coder_group_cuts
+    assert coder_group_cuts(53, 8) == [7, 14, 21, 28, 35, 42, 49, 53]
+    assert coder_group_cuts(224, 8) == [28, 56, 84, 112, 140, 168, 196, 224]
+    assert coder_group_cuts(3, 4) == [1, 2, 3] and coder_group_cuts(1, 4) == [1] and coder_group_cuts(0, 4) == []
+    assert coder_group_cuts(5, 1) == [5]
+    assert coder_group_cuts(53, (0.5, 0.75, 0.875, 0.9375, 1.0)) == [26, 40, 46, 50, 53]
+    assert coder_group_cuts(3, (0.5, 0.75, 1.0)) == [2, 3] and coder_group_cuts(1, (0.1, 0.2)) == [1]
+    for n in range(1, 60):
+        for g in (1, 2, 3, 4, 8, 16, (0.08, 0.31, 0.54, 0.77, 0.92, 1.0)):
+            c = coder_group_cuts(n, g)
+            assert c == sorted(set(c)) and c[-1] == n and c[0] >= 1
