@@ -69,6 +69,11 @@ def main():
                 ns = sum(dur[k]) / len(dur[k])
                 e['hbm_gb_per_s'] = round(e['hbm_bytes_per_launch'] / ns, 1)
                 e['frac_of_hbm_peak_8tb'] = round(e['hbm_bytes_per_launch'] / ns / 8000.0, 4)
+            if k == 'cdf_table_from_P_kernel' and 'hbm_write_bytes_per_launch' in e and dur[k]:
+                # every uint16 entry written is the sum of K = 10 sigmoids (BASELINE configs: prob.K = 10): SURVEY.md section 8d's exp/s figure
+                ns = sum(dur[k]) / len(dur[k])
+                e['table_entries_per_launch'] = int(e['hbm_write_bytes_per_launch'] / 2)
+                e['sigmoid_evals_per_s'] = round(e['hbm_write_bytes_per_launch'] / 2 * 10 / (ns * 1e-9), -9)
             out['decode_kernels'][k] = e
         else:
             out['kernels'][k] = e
