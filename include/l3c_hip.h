@@ -237,25 +237,10 @@ typedef struct {
 /* fp32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32; Cin % 16 == 0 (64 or 192 on this path). */
 int l3c_conv_mfma(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 /*
- * The same convolution for KS == 3, stride 1, dilation 1, 2 or 4 by Winograd F(2x2, 3x3): 2.25x fewer multiplications, the
- * 16 per-position GEMMs on the fp32 MFMA.  `packed_w` of the descriptor must come from l3c_conv_wino_pack_weights (the
- * transformed weights G g G^T, l3c_conv_wino_packed_words(Cout, Cin) floats).  Differs from l3c_conv_mfma by fp32 rounding.
- * Requirements (L3C_ERR_INVALID_ARG otherwise): Cin % 16 == 0; Cout % 4 == 0 (with PIXEL_SHUFFLE: % 16, dilation 1, no
- * RELU / RESIDUAL); every channel stride / offset a multiple of 4 and every pointer 16-byte aligned (16-byte accesses);
- * one image of each tensor below 2 GB; no epilogue bits other than L3C_EPI_*.
- * l3c_conv_wino_set_tiles_per_block: a block walks up to n horizontally adjacent 4 x 32 output tiles with its load pipeline
- * running through the tile boundaries; 0 (default, or the environment variable L3C_WINO_TPB at load time) picks n per launch
- * from the grid size.  The result does not depend on n bit for bit.  Process-wide; returns the previous value.
- */
-int64_t l3c_conv_wino_packed_words(int Cout, int Cin);
-int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
-int l3c_conv_wino(const l3c_conv_desc *desc_host, l3c_stream_t stream);
-int l3c_conv_wino_set_tiles_per_block(int n);
-/*
- * The same convolution by Winograd F(4x4, 3x3) (interpolation points 0, +-1, +-2, inf): 4x fewer multiplications than the direct
- * form, 1.78x fewer than F(2x2, 3x3); the 36 per-position GEMMs on v_mfma_f32_16x16x4_f32, output transform in registers.
+ * The same convolution by Winograd F(4x4, 3x3) (interpolation points 0, 1, -1, 1/2, -2, inf): 4x fewer multiplications than the
+ * direct form; the 36 per-position GEMMs on v_mfma_f32_16x16x4_f32, output transform in registers.
  * `packed_w` must come from l3c_conv_wino4_pack_weights (G g G^T computed in double precision, l3c_conv_wino4_packed_words(Cout,
- * Cin) floats).  Replaces the same cuDNN call sites as l3c_conv_wino (modules/edsr.py:63-89, net.py:136-148, :173-184,
+ * Cin) floats).  Replaces the cuDNN call sites of the 3x3 layers (modules/edsr.py:63-89, net.py:136-148, :173-184,
  * prob_clf.py:71-74); differs from the direct convolution by fp32 rounding (measured: the L3C forward stays within 5e-6 of the
  * fp32 reference relative to each tensor's largest magnitude, profiles/r03_wino_f43_numerics.log).  Cin % 16 == 0; input and
  * packed weights 16-byte aligned, input channel stride / offset multiples of 4; output / residual: any channel slice.

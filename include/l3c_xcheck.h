@@ -1,0 +1,36 @@
+/*
+ * l3c_xcheck.h -- C ABI of libl3c_hip_xcheck.so, a TEST-ONLY library (csrc/build.py builds it next to the product library; the
+ * product never loads it).  It holds the round-1/2 Winograd F(2x2,3x3) convolution kernel (csrc/conv_wino.hip), kept as an
+ * independent second implementation the tests compare the product's F(4x4,3x3) kernel with (tests/test_gpu_conv.py), plus the
+ * library-level entry points of l3c_api.hip (error text).  Same conventions as include/l3c_hip.h.
+ */
+#ifndef L3C_XCHECK_H_
+#define L3C_XCHECK_H_
+
+#include "l3c_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * The l3c_conv_mfma convolution for KS == 3, stride 1, dilation 1, 2 or 4 by Winograd F(2x2, 3x3): 2.25x fewer multiplications, the
+ * 16 per-position GEMMs on the fp32 MFMA.  `packed_w` of the descriptor must come from l3c_conv_wino_pack_weights (the
+ * transformed weights G g G^T, l3c_conv_wino_packed_words(Cout, Cin) floats).  Differs from l3c_conv_mfma by fp32 rounding.
+ * Requirements (L3C_ERR_INVALID_ARG otherwise): Cin % 16 == 0; Cout % 4 == 0 (with PIXEL_SHUFFLE: % 16, dilation 1, no
+ * RELU / RESIDUAL); every channel stride / offset a multiple of 4 and every pointer 16-byte aligned (16-byte accesses);
+ * one image of each tensor below 2 GB; no epilogue bits other than L3C_EPI_*.
+ * l3c_conv_wino_set_tiles_per_block: a block walks up to n horizontally adjacent 4 x 32 output tiles with its load pipeline
+ * running through the tile boundaries; 0 (default, or the environment variable L3C_WINO_TPB at load time) picks n per launch
+ * from the grid size.  The result does not depend on n bit for bit.  Process-wide; returns the previous value.
+ */
+int64_t l3c_conv_wino_packed_words(int Cout, int Cin);
+int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
+int l3c_conv_wino(const l3c_conv_desc *desc_host, l3c_stream_t stream);
+int l3c_conv_wino_set_tiles_per_block(int n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -78,10 +78,6 @@ PROTOTYPES = {
     'l3c_conv_packed_words': (c_i64, [c_int, c_int, c_int]),
     'l3c_conv_pack_weights': (c_int, [c_vp, c_int, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_mfma': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
-    'l3c_conv_wino_packed_words': (c_i64, [c_int, c_int]),
-    'l3c_conv_wino_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
-    'l3c_conv_wino': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
-    'l3c_conv_wino_set_tiles_per_block': (c_int, [c_int]),
     'l3c_conv_wino4_packed_words': (c_i64, [c_int, c_int]),
     'l3c_conv_wino4_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_wino4': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
@@ -102,7 +98,17 @@ PROTOTYPES = {
     'l3c_sym_to_bn': (c_int, [c_vp, c_i64, c_f32, c_f32, c_vp, c_vp]),
 }
 
+# include/l3c_xcheck.h: the TEST-ONLY cross-check library (round-1/2 Winograd F(2x2,3x3) kernel); see load_xcheck()
+XCHECK_PROTOTYPES = {
+    'l3c_conv_wino_packed_words': (c_i64, [c_int, c_int]),
+    'l3c_conv_wino_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    'l3c_conv_wino': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
+    'l3c_conv_wino_set_tiles_per_block': (c_int, [c_int]),
+}
+XCHECK_LIB_PATH = os.path.join(_HERE, 'csrc', 'libl3c_hip_xcheck.so')
+
 _lib = None
+_xcheck = None
 
 
 def load():
@@ -120,6 +126,28 @@ def load():
             raise L3CError('ABI version mismatch: library {} != binding 1'.format(lib.l3c_abi_version()))
         _lib = lib
     return _lib
+
+
+def load_xcheck():
+    """libl3c_hip_xcheck.so -- for tests and development probes ONLY: an independent second implementation of the 3x3 convolution
+    to compare the product's kernels with.  Nothing under l3c-pytorch_amd/ calls this on the product path."""
+    global _xcheck
+    if _xcheck is None:
+        if not os.path.isfile(XCHECK_LIB_PATH):
+            raise L3CError('libl3c_hip_xcheck.so not found at {} -- build it with `python l3c-pytorch_amd/csrc/build.py`'.format(XCHECK_LIB_PATH))
+        lib = ctypes.CDLL(XCHECK_LIB_PATH)
+        lib.l3c_last_error.restype = ctypes.c_char_p
+        for name, (res, args) in XCHECK_PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _xcheck = lib
+    return _xcheck
+
+
+def call_xcheck(name, *args):
+    rc = getattr(load_xcheck(), name)(*args)
+    if rc != 0:
+        raise L3CError('libl3c_hip_xcheck: {} (status {})'.format(load_xcheck().l3c_last_error().decode(), rc))
 
 
 def check(rc):

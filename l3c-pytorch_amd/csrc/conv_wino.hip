@@ -26,6 +26,7 @@
 // A dilated conv is the dense conv on each of the dil x dil interleaved sub-grids of the image: same kernel, strided indexing.
 // fp32 throughout; the result differs from the direct convolution by rounding only (transform coefficients are 1, 1/2).
 #include "l3c_common.h"
+#include "../../include/l3c_xcheck.h"
 
 #include <stdlib.h>
 

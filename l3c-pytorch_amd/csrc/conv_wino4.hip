@@ -158,7 +158,10 @@ static_assert(L3C_W4_RING == 4 || L3C_W4_RING == 6, "ring depth");
 // slot of pair q (numbered on into the next chunk) in a chunk of buffer parity par: 18 pairs per chunk = 2 mod 4, 0 mod 6
 __device__ __forceinline__ constexpr int ring_slot(int q, int par) { return L3C_W4_RING == 4 ? ((q + 2 * par) & 3) : q % 6; }
 
-template <bool RELU, bool RES, bool SHUFFLE>
+// POLY: the polyphase forms of a stride-2 convolution (l3c_conv_wino4_phase / _stride2) get an instantiation of their own, so that the
+// profiler's kernel names tell the 5x5 stride-2 launches from the 3x3 ones (tools/pmc_bench.py).  A name tag only: the body keeps reading
+// p.poly at run time (folding it changed the register allocation of the ReLU variant: 255 -> 256 VGPRs + 2 spills)
+template <bool RELU, bool RES, bool SHUFFLE, bool POLY>
 __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -706,10 +709,11 @@ static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int 
     p.div_groups_x = w4_div((unsigned)p.groups_x);
     p.div_chunks = w4_div((unsigned)p.n_chunks_o);
     typedef void (*kernel_t)(const Wino4Params);
-    static const kernel_t variants[5] = {conv_wino4_kernel<false, false, false>, conv_wino4_kernel<true, false, false>,
-                                         conv_wino4_kernel<false, true, false>, conv_wino4_kernel<true, true, false>,
-                                         conv_wino4_kernel<false, false, true>};
-    static bool attr_set[64][5] = {};   // > 64 KB of dynamic LDS needs the opt-in, per device
+    static const kernel_t variants[7] = {conv_wino4_kernel<false, false, false, false>, conv_wino4_kernel<true, false, false, false>,
+                                         conv_wino4_kernel<false, true, false, false>, conv_wino4_kernel<true, true, false, false>,
+                                         conv_wino4_kernel<false, false, true, false>,
+                                         conv_wino4_kernel<false, false, false, true>, conv_wino4_kernel<false, true, false, true>};
+    static bool attr_set[64][7] = {};   // > 64 KB of dynamic LDS needs the opt-in, per device
     int dev = 0;
     {
         const int rc = l3c::check_hip(hipGetDevice(&dev), "hipGetDevice");
@@ -717,7 +721,7 @@ static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int 
     }
     L3C_REQUIRE(dev >= 0 && dev < 64, "device index out of range");
     const bool relu = d->epilogue & L3C_EPI_RELU, res = d->epilogue & L3C_EPI_RESIDUAL, shuffle = d->epilogue & L3C_EPI_PIXEL_SHUFFLE;
-    const int v = shuffle ? 4 : (relu ? 1 : 0) + (res ? 2 : 0);
+    const int v = poly ? (res ? 6 : 5) : shuffle ? 4 : (relu ? 1 : 0) + (res ? 2 : 0);   // (the polyphase forms: bias (+ residual) only)
     if (!attr_set[dev][v]) {
         const int rc = l3c::check_hip(hipFuncSetAttribute(reinterpret_cast<const void *>(variants[v]),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, W4_LDS_BYTES),

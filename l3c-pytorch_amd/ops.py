@@ -8,19 +8,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, call, ptr, stream
 
-_CONV_IMPL = os.environ.get('L3C_CONV_IMPL', 'mfma')   # 'direct' = plain-VALU cross-check kernel (debugging)
-# 3x3 / stride 1 layers (dilation 1, 2, 4) run as Winograd F(2x2,3x3) on the MFMA (csrc/conv_wino.hip) unless L3C_CONV_WINO=0
-_CONV_WINO = os.environ.get('L3C_CONV_WINO', '1') != '0'
-# ... by default in its F(4x4,3x3) form (csrc/conv_wino4.hip: 1.78x fewer multiplications again) unless L3C_CONV_WINO4=0
-_CONV_WINO4 = os.environ.get('L3C_CONV_WINO4', '1') != '0'
-# 5x5 / stride 2 layers (the encoders' `down`) run as four 3x3 polyphase convolutions on the F(4x4,3x3) kernel unless L3C_CONV_POLY5=0
-_CONV_POLY5 = os.environ.get('L3C_CONV_POLY5', '1') != '0'
-_CONV_POLY5_FUSED = os.environ.get('L3C_CONV_POLY5_FUSED', '1') != '0'   # all four phases in one launch (0: four accumulating launches)
-# 1x1 layers with Cin % 64 == 0 and Cout <= 160 (the 192 -> Kp classifier output) run on the pointwise kernel (csrc/conv_pw.hip)
-# unless L3C_CONV_PW=0
-_CONV_PW = os.environ.get('L3C_CONV_PW', '1') != '0'
-
-# Optional per-launch timing of the MFMA conv kernel (bench.py's roofline leg): when PROFILE is a list, every conv launch
+# Optional per-launch timing of the MFMA conv kernels (bench.py's roofline leg): when PROFILE is a list, every conv launch
 # appends (kernel key, algorithmic FLOPs, algorithmic HBM bytes, start event, end event), the events being recorded on the launch
 # stream.
 PROFILE = None
@@ -28,63 +16,76 @@ PROFILE_DETAIL = bool(os.environ.get('L3C_PROFILE_DETAIL'))   # split the keys b
 
 
 # ---- convolution stack ------------------------------------------------------------------------------------------------
+#
+# ONE dispatch (no environment switches: encoder and decoder of a file must compute bit-identical P, so the kernel a layer runs on
+# is a function of the layer and the tensors alone):
+#   3x3 stride 1 (dilation 1, 2, 4), Cin % 16 == 0   -> Winograd F(4x4,3x3), csrc/conv_wino4.hip
+#   5x5 stride 2, even input size                     -> four 3x3 polyphase convolutions in one launch of the same kernel
+#   1x1, Cin % 64 == 0, Cout <= 160, bias only        -> pointwise GEMM, csrc/conv_pw.hip
+#   anything else with Cin % 16 == 0                  -> implicit GEMM, csrc/conv_mfma.hip (odd sizes, unaligned channel slices)
+# `impl=` forces one kernel for the tests and probes: 'wino4', 'poly5', 'poly5x4' (four accumulating phase launches), 'gemm',
+# 'direct' (plain-VALU cross-check in the product library), 'wino2' (the F(2x2,3x3) kernel of the TEST-ONLY libl3c_hip_xcheck.so).
 
 
 class PackedConv(object):
-    """One conv layer resident on the device: OIHW weights, bias, and the MFMA-fragment-packed copy."""
+    """One conv layer resident on the device: OIHW weights, bias, and the packed copies of the kernels that can run it."""
 
     def __init__(self, weight, bias, stride=1, dilation=1):
         _lib.require_gpu()
+        lib = _lib.load()
         self.Cout, self.Cin, self.KS, _ = weight.shape
         self.stride, self.dilation = stride, dilation
         self.weight = weight.detach().to('cuda', torch.float32).contiguous()
         self.bias = bias.detach().to('cuda', torch.float32).contiguous()
-        self.packed = None
+        self.packed = None            # implicit GEMM (generic form)
         if self.Cin % 16 == 0:
-            n = _lib.load().l3c_conv_packed_words(self.Cout, self.Cin, self.KS)
-            self.packed = torch.empty(n, dtype=torch.float32, device='cuda')
+            self.packed = torch.empty(lib.l3c_conv_packed_words(self.Cout, self.Cin, self.KS), dtype=torch.float32, device='cuda')
             call('l3c_conv_pack_weights', ptr(self.weight), self.Cout, self.Cin, self.KS, ptr(self.packed), stream())
-        self.packed_wino = None
-        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 16 == 0 and self.Cout % 4 == 0:
-            n = _lib.load().l3c_conv_wino_packed_words(self.Cout, self.Cin)
-            self.packed_wino = torch.empty(n, dtype=torch.float32, device='cuda')
-            call('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino), stream())
-        self.packed_wino4 = None
-        if _CONV_WINO and self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 16 == 0:
-            n = _lib.load().l3c_conv_wino4_packed_words(self.Cout, self.Cin)
-            self.packed_wino4 = torch.empty(n, dtype=torch.float32, device='cuda')
-            call('l3c_conv_wino4_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_wino4), stream())
-
-        # 5x5 stride 2 padding 2 = four 3x3 stride-1 convolutions of the input's 2x2 phases (include/l3c_hip.h, l3c_conv_wino4_phase):
-        # phase kernel w_ab[u][v] = w[2u+a][2v+b], zero where the index exceeds 4
-        self.packed_poly = None
+        self.packed_wino4 = None      # G g G^T of F(4x4,3x3)
+        if self.KS == 3 and stride == 1 and dilation in (1, 2, 4) and self.Cin % 16 == 0:
+            self.packed_wino4 = self._pack_wino4(self.weight)
+        # 5x5 stride 2 padding 2 = four 3x3 stride-1 convolutions of the input's 2x2 phases (include/l3c_hip.h, l3c_conv_wino4_stride2):
+        # phase kernel w_ab[u][v] = w[2u+a][2v+b], zero where the index exceeds 4; all four in ONE launch: the phase kernels
+        # concatenated along the input-channel axis
+        self.packed_poly_fused = None
         if self.KS == 5 and stride == 2 and dilation == 1 and self.Cin % 16 == 0 and self.Cout % 4 == 0:
-            self.packed_poly = []
-            n = _lib.load().l3c_conv_wino4_packed_words(self.Cout, self.Cin)
-            for a in (0, 1):
-                for b in (0, 1):
-                    wp = torch.zeros(self.Cout, self.Cin, 3, 3, dtype=torch.float32, device='cuda')
-                    sub = self.weight[:, :, a::2, b::2]
-                    wp[:, :, :sub.shape[2], :sub.shape[3]] = sub
-                    packed = torch.empty(n, dtype=torch.float32, device='cuda')
-                    call('l3c_conv_wino4_pack_weights', ptr(wp), self.Cout, self.Cin, ptr(packed), stream())
-                    self.packed_poly.append(packed)
-            self.zero_bias = torch.zeros(self.Cout, dtype=torch.float32, device='cuda')
-            # all four phases in ONE launch (l3c_conv_wino4_stride2): the phase kernels concatenated along the input-channel axis
             w_cat = torch.zeros(self.Cout, 4 * self.Cin, 3, 3, dtype=torch.float32, device='cuda')
-            for a in (0, 1):
-                for b in (0, 1):
-                    sub = self.weight[:, :, a::2, b::2]
-                    w_cat[:, (2 * a + b) * self.Cin:(2 * a + b + 1) * self.Cin, :sub.shape[2], :sub.shape[3]] = sub
-            n4 = _lib.load().l3c_conv_wino4_packed_words(self.Cout, 4 * self.Cin)
-            self.packed_poly_fused = torch.empty(n4, dtype=torch.float32, device='cuda')
-            call('l3c_conv_wino4_pack_weights', ptr(w_cat), self.Cout, 4 * self.Cin, ptr(self.packed_poly_fused), stream())
-
+            for k, sub in enumerate(self._phase_kernels()):
+                w_cat[:, k * self.Cin:(k + 1) * self.Cin, :sub.shape[2], :sub.shape[3]] = sub
+            self.packed_poly_fused = self._pack_wino4(w_cat)
         self.packed_pw = None
-        if _CONV_PW and self.KS == 1 and stride == 1 and self.Cin % 64 == 0 and self.Cout <= 160:
-            n = _lib.load().l3c_conv_pw_packed_words(self.Cout, self.Cin)
-            self.packed_pw = torch.empty(n, dtype=torch.float32, device='cuda')
+        if self.KS == 1 and stride == 1 and self.Cin % 64 == 0 and self.Cout <= 160:
+            self.packed_pw = torch.empty(lib.l3c_conv_pw_packed_words(self.Cout, self.Cin), dtype=torch.float32, device='cuda')
             call('l3c_conv_pw_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_pw), stream())
+        self._packed_poly = self._packed_wino2 = self._zero_bias = None
+
+    def _pack_wino4(self, w):
+        packed = torch.empty(_lib.load().l3c_conv_wino4_packed_words(w.shape[0], w.shape[1]), dtype=torch.float32, device='cuda')
+        call('l3c_conv_wino4_pack_weights', ptr(w.contiguous()), w.shape[0], w.shape[1], ptr(packed), stream())
+        return packed
+
+    def _phase_kernels(self):
+        return [self.weight[:, :, a::2, b::2] for a in (0, 1) for b in (0, 1)]
+
+    def packed_poly(self):
+        """tests only ('poly5x4'): the four phase kernels packed one by one, for l3c_conv_wino4_phase"""
+        if self._packed_poly is None:
+            self._packed_poly = []
+            for sub in self._phase_kernels():
+                wp = torch.zeros(self.Cout, self.Cin, 3, 3, dtype=torch.float32, device='cuda')
+                wp[:, :, :sub.shape[2], :sub.shape[3]] = sub
+                self._packed_poly.append(self._pack_wino4(wp))
+            self._zero_bias = torch.zeros(self.Cout, dtype=torch.float32, device='cuda')
+        return self._packed_poly
+
+    def packed_wino2(self):
+        """tests only ('wino2'): G g G^T of the F(2x2,3x3) kernel in the cross-check library"""
+        if self._packed_wino2 is None:
+            assert self.KS == 3 and self.stride == 1 and self.Cin % 16 == 0 and self.Cout % 4 == 0
+            n = _lib.load_xcheck().l3c_conv_wino_packed_words(self.Cout, self.Cin)
+            self._packed_wino2 = torch.empty(n, dtype=torch.float32, device='cuda')
+            _lib.call_xcheck('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self._packed_wino2), stream())
+        return self._packed_wino2
 
     def out_hw(self, H, W):
         pad = self.KS // 2 if self.dilation == 1 else self.dilation
@@ -92,48 +93,44 @@ class PackedConv(object):
         return (H + 2 * pad - ext) // self.stride + 1, (W + 2 * pad - ext) // self.stride + 1
 
 
-def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, relu=False, pixel_shuffle=False,
-         impl=None):
-    """x: (B,H,W,cstride) pixel-major fp32.  Returns `out` ((B,Ho,Wo,Cout) freshly allocated when None)."""
+def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, relu=False, pixel_shuffle=False, impl=None):
+    """x: (B,H,W,cstride) pixel-major fp32.  Returns `out` ((B,Ho,Wo,Cout) freshly allocated when None).  impl: None = the
+    product's dispatch (see above); a name forces one kernel (tests, probes)."""
     B, H, W, cstride = x.shape
     Ho, Wo = layer.out_hw(H, W)
     if out is None:
         out = (torch.empty(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
                else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
-    impl = impl or _CONV_IMPL
-    # The Winograd kernels store / load 16 bytes per lane: channel strides and offsets of the output (and residual) slices must be
-    # multiples of 4, the pointers 16-byte aligned, Cout a multiple of 4 (pixel shuffle: 16); they address one input image with
-    # 32-bit offsets (< 2 GB) and have no pixel shuffle combined with dilation, ReLU or a residual.  Anything else goes to the
-    # implicit-GEMM kernel (64-bit addressing, 4-byte stores) -- the same preconditions l3c_conv_wino / l3c_conv_wino4 check.
+    assert impl in (None, 'wino4', 'wino2', 'gemm', 'poly5', 'poly5x4', 'direct'), impl
+
+    # The Winograd kernel stores / loads 16 bytes per lane: channel strides and offsets of the output (and residual) slices must be
+    # multiples of 4, the pointers 16-byte aligned, Cout a multiple of 4 (pixel shuffle: 16); it addresses one input image with
+    # 32-bit offsets (< 2 GB) and has no pixel shuffle combined with dilation, ReLU or a residual -- the preconditions
+    # l3c_conv_wino4 checks.  Anything else goes to the implicit-GEMM kernel (64-bit addressing, 4-byte stores).
     def _aligned(t, coff):
         return t is None or (t.shape[-1] % 4 == 0 and coff % 4 == 0 and t.data_ptr() % 16 == 0)
-    wino_ok = (layer.KS == 3 and layer.stride == 1 and _aligned(out, out_coff) and _aligned(residual, res_coff) and
-               x.data_ptr() % 16 == 0 and cstride % 4 == 0 and in_coff % 4 == 0 and H * W * cstride * 4 < 0x7ffffff0 and
+    in_ok = x.data_ptr() % 16 == 0 and cstride % 4 == 0 and in_coff % 4 == 0 and H * W * cstride * 4 < 0x7ffffff0
+    wino_ok = (layer.KS == 3 and layer.stride == 1 and in_ok and _aligned(out, out_coff) and _aligned(residual, res_coff) and
                layer.Cout % (16 if pixel_shuffle else 4) == 0 and
                not (pixel_shuffle and (relu or residual is not None or layer.dilation != 1)))
-    # impl: 'mfma' = the product's dispatch; 'wino4' / 'wino2' / 'gemm' force one kernel (tests, probes); 'direct' = VALU cross-check
-    poly = ((impl in ('poly5', 'poly5x4') or (impl == 'mfma' and _CONV_POLY5 and _CONV_WINO4)) and getattr(layer, 'packed_poly', None) is not None and
-            H % 2 == 0 and W % 2 == 0 and _aligned(out, out_coff) and residual is None and not relu and not pixel_shuffle and
-            x.data_ptr() % 16 == 0 and cstride % 4 == 0 and in_coff % 4 == 0 and H * W * cstride * 4 < 0x7ffffff0)
-    if impl in ('poly5', 'poly5x4'):
-        assert poly, 'this layer has no polyphase form'
-    if poly:
-        return _conv_poly5(x, layer, out, in_coff, out_coff, fused=(impl != 'poly5x4' and _CONV_POLY5_FUSED))
-    wino4 = (impl == 'wino4' or (impl == 'mfma' and _CONV_WINO4)) and layer.packed_wino4 is not None and wino_ok
-    wino = not wino4 and impl in ('mfma', 'wino2') and layer.packed_wino is not None and wino_ok
-    if impl in ('wino4', 'wino2'):
-        assert wino4 or wino, 'this layer / epilogue has no Winograd form'
-    if impl in ('wino4', 'wino2', 'gemm'):
-        impl = 'mfma'
-        pw_allowed = False
+    poly_ok = (layer.packed_poly_fused is not None and H % 2 == 0 and W % 2 == 0 and in_ok and _aligned(out, out_coff) and
+               residual is None and not relu and not pixel_shuffle)
+    if impl in ('poly5', 'poly5x4') or (impl is None and poly_ok):
+        assert poly_ok, 'this layer / tensor has no polyphase form'
+        return _conv_poly5(x, layer, out, in_coff, out_coff, fused=impl != 'poly5x4')
+    if impl is None:
+        kernel = ('wino4' if layer.packed_wino4 is not None and wino_ok else
+                  'pw' if layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None) else 'gemm')
     else:
-        pw_allowed = True
-    if impl == 'mfma' and not (wino or wino4) and layer.packed is None and layer.KS == 3:
-        raise _lib.L3CError('3x3 convolution outside the Winograd kernels\' preconditions and no implicit-GEMM form (Cin % 16 != 0)')
-    pw = pw_allowed and not wino4 and impl == 'mfma' and layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None)
+        kernel = impl
+    if kernel in ('wino4', 'wino2'):
+        assert wino_ok and (kernel == 'wino2' or layer.packed_wino4 is not None), 'this layer / epilogue has no Winograd form'
+    if kernel == 'gemm' and layer.packed is None:
+        raise _lib.L3CError('convolution outside every MFMA kernel\'s preconditions (Cin % 16 != 0)')
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
-    d.packed_w = ptr(layer.packed_wino4 if wino4 else layer.packed_wino if wino else layer.packed_pw if pw else layer.packed if impl == 'mfma' else layer.weight)
+    d.packed_w = ptr({'wino4': layer.packed_wino4, 'pw': layer.packed_pw, 'gemm': layer.packed, 'direct': layer.weight}[kernel]
+                     if kernel != 'wino2' else layer.packed_wino2())
     d.bias = ptr(layer.bias)
     d.residual = ptr(residual, torch.float32) if residual is not None else None
     d.res_cstride = residual.shape[-1] if residual is not None else 0
@@ -143,21 +140,23 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     d.KS, d.stride, d.dilation = layer.KS, layer.stride, layer.dilation
     d.epilogue = ((_lib.EPI_RELU if relu else 0) | (_lib.EPI_RESIDUAL if residual is not None else 0) |
                   (_lib.EPI_PIXEL_SHUFFLE if pixel_shuffle else 0))
-    if PROFILE is not None and impl == 'mfma':
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        call('l3c_conv_wino4' if wino4 else 'l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma', d, stream())
-        e1.record()
-        key = ('conv_wino4_kernel' if wino4 else 'conv_wino_kernel' if wino else 'conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
-               'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
-        if PROFILE_DETAIL:
-            key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '',
-                                              ' shuffle' if pixel_shuffle else '')
-        nbytes = 4.0 * B * (H * W * layer.Cin + Ho * Wo * layer.Cout * (2 if residual is not None else 1))   # in + out (+ residual), once
-        PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1))
+    if kernel == 'wino2':
+        _lib.call_xcheck('l3c_conv_wino', d, stream())
         return out
-    call('l3c_conv_wino4' if wino4 else 'l3c_conv_wino' if wino else 'l3c_conv_pw' if pw else 'l3c_conv_mfma' if impl == 'mfma' else 'l3c_conv_direct',
-         d, stream())
+    entry = {'wino4': 'l3c_conv_wino4', 'pw': 'l3c_conv_pw', 'gemm': 'l3c_conv_mfma', 'direct': 'l3c_conv_direct'}[kernel]
+    if PROFILE is None or kernel == 'direct':
+        call(entry, d, stream())
+        return out
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call(entry, d, stream())
+    e1.record()
+    key = ('conv_wino4_kernel' if kernel == 'wino4' else 'conv_lds_kernel<3,{}>'.format(layer.dilation) if layer.KS == 3 else
+           'conv k{} s{} (mfma)'.format(layer.KS, layer.stride))   # 3x3: the kernel name rocprofv3 reports
+    if PROFILE_DETAIL:
+        key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '', ' shuffle' if pixel_shuffle else '')
+    nbytes = 4.0 * B * (H * W * layer.Cin + Ho * Wo * layer.Cout * (2 if residual is not None else 1))   # in + out (+ residual), once
+    PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1))
     return out
 
 
@@ -180,8 +179,8 @@ def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True):
     for k, (a, b) in enumerate(() if fused else ((0, 0), (0, 1), (1, 0), (1, 1))):
         d = ConvDesc()
         d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
-        d.packed_w = ptr(layer.packed_poly[k])
-        d.bias = ptr(layer.bias if k == 0 else layer.zero_bias)
+        d.packed_w = ptr(layer.packed_poly()[k])
+        d.bias = ptr(layer.bias if k == 0 else layer._zero_bias)
         d.residual = ptr(out, torch.float32) if k else None
         d.res_cstride, d.res_coff = (out.shape[-1], out_coff) if k else (0, 0)
         d.out, d.out_cstride, d.out_coff = ptr(out, torch.float32), out.shape[-1], out_coff

@@ -53,10 +53,10 @@ def _check_intervals(table, sym):
     word stores c_high - 1, where an empty interval at 0 is indistinguishable from c_high = 65536): c_low = cdf[sym], c_high =
     cdf[sym + 1], read as uint16, with 0 standing for 65536 only at the top symbol (torchac.cpp:181)."""
     N, Lp = table.shape
-    t = table.to(torch.int32) & 0xFFFF
     s = sym.reshape(-1, 1).long()
-    lo = t.gather(1, s)[:, 0]
-    hi = t.gather(1, s + 1)[:, 0]
+    # gather on the int16 table first: two N-vectors, not two N x Lp int32 copies of the table (0.8 GB for one 768x512 channel)
+    lo = table.gather(1, s)[:, 0].to(torch.int32) & 0xFFFF
+    hi = table.gather(1, s + 1)[:, 0].to(torch.int32) & 0xFFFF
     hi = torch.where(s[:, 0] == Lp - 2, torch.full_like(hi, 65536), hi)
     if bool((hi <= lo).any()):
         raise ValueError('cdf is not increasing at a coded symbol (c_high <= c_low): the stream would not be decodable')

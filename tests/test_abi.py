@@ -10,8 +10,8 @@ from l3c_pytorch_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, 'include', 'l3c_hip.h')).read()
+def _declared(header='l3c_hip.h'):
+    src = open(os.path.join(ROOT, 'include', header)).read()
     src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
     return sorted(set(re.findall(r'\b(l3c_[a-z0-9_]+)\s*\(', src)))
 
@@ -26,6 +26,15 @@ def test_library_is_built_and_exports_every_declared_symbol():
         assert hasattr(lib, n), n
     assert sorted(_lib.PROTOTYPES) == names
     assert lib.l3c_abi_version() == 1
+    # the product library holds ONE generation of convolution kernels: the F(2x2,3x3) cross-check kernel lives in the test-only
+    # library (include/l3c_xcheck.h), which exports exactly what that header declares
+    assert not any(n.startswith('l3c_conv_wino_') or n == 'l3c_conv_wino' for n in names)
+    assert not hasattr(lib, 'l3c_conv_wino')
+    x = _lib.load_xcheck()
+    xnames = _declared('l3c_xcheck.h')
+    assert sorted(_lib.XCHECK_PROTOTYPES) == xnames and len(xnames) == 4
+    for n in xnames:
+        assert hasattr(x, n), n
 
 
 def test_pure_host_entry_points():
@@ -50,10 +59,14 @@ def test_argument_validation_of_every_family_precedes_any_launch():
     well-aligned non-null pointers stand in for device memory (they are never dereferenced on these paths)."""
     import ctypes
     lib = _lib.load()
+    xlib = _lib.load_xcheck()
     fake = 0x1000
 
     def err():
         return lib.l3c_last_error().decode()
+
+    def xerr():
+        return xlib.l3c_last_error().decode()
 
     # range coder
     assert lib.l3c_ac_decode(fake, 300, 300, fake, fake, fake, 1, 1, 1, fake, None) == -1 and 'Lp out of range' in err()
@@ -80,23 +93,23 @@ def test_argument_validation_of_every_family_precedes_any_launch():
     d.inp = d.packed_w = d.bias = d.out = fake
     d.B, d.Hin, d.Win, d.Cin, d.Cout, d.KS, d.stride, d.dilation = 1, 8, 8, 64, 64, 5, 1, 1
     d.in_cstride = 64
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '3x3, stride 1 only' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '3x3, stride 1 only' in xerr()
     d.KS, d.dilation = 3, 3
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'dilation must be' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'dilation must be' in xerr()
     d.dilation, d.Cin = 1, 60
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 16' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 16' in xerr()
     d.Cin, d.out_cstride = 64, 62
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '16-byte stores' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '16-byte stores' in xerr()
     d.out_cstride, d.out = 64, fake + 4
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '16-byte aligned' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and '16-byte aligned' in xerr()
     d.out, d.Cout = fake, 62
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 4' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'multiple of 4' in xerr()
     d.Cout, d.epilogue = 64, 0x100
-    assert lib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'unknown epilogue bits' in err()
+    assert xlib.l3c_conv_wino(ctypes.byref(d), None) == -1 and 'unknown epilogue bits' in xerr()
     assert lib.l3c_conv_mfma(ctypes.byref(d), None) == -1 and 'unknown epilogue bits' in err()      # no probe kernels in the product
     d.epilogue = 0
-    assert lib.l3c_conv_wino_set_tiles_per_block(2) == 0 and lib.l3c_conv_wino_set_tiles_per_block(0) == 2
-    assert lib.l3c_conv_wino_packed_words(64, 64) == 16 * 64 * 64 and lib.l3c_conv_wino_packed_words(120, 64) == 16 * 128 * 64
+    assert xlib.l3c_conv_wino_set_tiles_per_block(2) == 0 and xlib.l3c_conv_wino_set_tiles_per_block(0) == 2
+    assert xlib.l3c_conv_wino_packed_words(64, 64) == 16 * 64 * 64 and xlib.l3c_conv_wino_packed_words(120, 64) == 16 * 128 * 64
     # container
     sc = (_lib.ContainerScale * 1)(_lib.ContainerScale(fake, fake, 6, 5, 8, 8))
     assert lib.l3c_container_write(sc, 1, 2, fake, fake, fake, None) == -1 and '4-byte aligned' in err()

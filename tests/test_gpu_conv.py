@@ -45,7 +45,7 @@ def test_conv_mfma_vs_torch(KS, stride, dil, Cin, Cout, B, H, W):
     b = torch.randn(Cout, generator=g)
     ref = _ref_conv(x, w, b, stride, dil)
     layer = ops.PackedConv(w, b, stride=stride, dilation=dil)
-    IMPL = 'gemm' if KS in (3, 5) else 'mfma'     # 3x3, 5x5: the implicit-GEMM kernel (the product dispatches them to Winograd forms)
+    IMPL = 'gemm' if KS in (3, 5) else None       # 3x3, 5x5: the implicit-GEMM kernel (the product dispatches them to Winograd forms)
     got = ops.conv(_nhwc(x).cuda(), layer, impl=IMPL).cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     err = (got - ref).abs().max().item()
@@ -61,7 +61,7 @@ def test_conv_mfma_vs_torch(KS, stride, dil, Cin, Cout, B, H, W):
 
 
 def test_conv_epilogues():
-    """the product's dispatch (3x3 stride 1 -> Winograd F(4x4,3x3): within 1e-4 of torch's fp32 conv for unit-scale data)."""
+    """the product's dispatch (3x3 stride 1 -> Winograd F(4x4,3x3): within 3e-5 of torch's fp32 conv for unit-scale data)."""
     from l3c_pytorch_amd import ops
     g = torch.Generator().manual_seed(1)
     B, H, W = 2, 12, 40
@@ -73,20 +73,20 @@ def test_conv_epilogues():
     xd, rd = _nhwc(x).cuda(), _nhwc(res).cuda()
     ref = _ref_conv(x, w, b, 1, 1)
     got = ops.conv(xd, layer, relu=True).cpu().permute(0, 3, 1, 2)
-    assert (got - F.relu(ref)).abs().max() < 1e-4
+    assert (got - F.relu(ref)).abs().max() < 3e-5
     got = ops.conv(xd, layer, residual=rd).cpu().permute(0, 3, 1, 2)
-    assert (got - (ref + res)).abs().max() < 1e-4
+    assert (got - (ref + res)).abs().max() < 3e-5
     # channel-slice output (the atrous branches write into the 192-wide concat buffer)
     cat = torch.zeros(B, H, W, 192, device='cuda')
     ops.conv(xd, layer, out=cat, out_coff=64)
-    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2) - ref).abs().max() < 1e-4
+    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2) - ref).abs().max() < 3e-5
     assert float(cat[..., :64].abs().max()) == 0 and float(cat[..., 128:].abs().max()) == 0
     # pixel shuffle epilogue == nn.PixelShuffle(2) of the 256-channel conv (edsr.py:98-99)
     w4 = torch.randn(256, 64, 3, 3, generator=g) / 24
     b4 = torch.randn(256, generator=g)
     up = ops.conv(xd, ops.PackedConv(w4, b4), pixel_shuffle=True).cpu().permute(0, 3, 1, 2)
     ref_up = F.pixel_shuffle(_ref_conv(x, w4, b4, 1, 1), 2)
-    assert up.shape == ref_up.shape and (up - ref_up).abs().max() < 1e-4
+    assert up.shape == ref_up.shape and (up - ref_up).abs().max() < 3e-5
 
 
 def test_rgb_head_vs_torch(synthetic_l3c):
@@ -180,7 +180,7 @@ def test_winograd_conv_vs_implicit_gemm_and_fp64(dil, Cin, Cout, B, H, W, relu, 
     if shuffle:
         ref = F.pixel_shuffle(ref, 2)
     layer = ops.PackedConv(w, b, dilation=dil)
-    assert layer.packed_wino is not None
+    assert layer.packed_wino2() is not None            # (the test-only cross-check library, include/l3c_xcheck.h)
     kw = dict(relu=relu, residual=_nhwc(r).cuda() if res else None, pixel_shuffle=shuffle)
     got = ops.conv(_nhwc(x).cuda(), layer, impl='wino2', **kw).cpu().permute(0, 3, 1, 2)          # l3c_conv_wino
     assert got.shape == ref.shape
@@ -201,7 +201,7 @@ def test_winograd_conv_vs_implicit_gemm_and_fp64(dil, Cin, Cout, B, H, W, relu, 
 def wino_tpb():
     """l3c_conv_wino_set_tiles_per_block for the duration of a test (0 = pick per launch)."""
     from l3c_pytorch_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_xcheck()
     prev = lib.l3c_conv_wino_set_tiles_per_block(0)
     yield lib.l3c_conv_wino_set_tiles_per_block
     lib.l3c_conv_wino_set_tiles_per_block(prev)
@@ -266,7 +266,7 @@ def test_winograd_at_the_headline_layer_sizes(wino_tpb, dil, Cout, B, H, W, shuf
     gemm = ops.conv(xd, layer, impl='gemm', **kw)
     assert (got - gemm).abs().max().item() < 3e-5
     f4 = ops.conv(xd, layer, impl='wino4', **kw)                  # the F(4x4,3x3) kernel at the same sizes
-    assert (f4 - gemm).abs().max().item() < 1e-4
+    assert (f4 - gemm).abs().max().item() < 3e-5
     wino_tpb(1)
     assert torch.equal(ops.conv(xd, layer, impl='wino2', **kw), got)
     # fp64 on a window that contains the image's bottom-right corner
@@ -353,7 +353,7 @@ def test_winograd_random_shapes_vs_implicit_gemm(wino_tpb):
         ops.conv(x, layer, out=out4, out_coff=4, impl='wino4', **kw)
         got4 = out4[..., 4:4 + co]
         assert not bool(torch.isnan(got4).any()), ('f4', case, dil, H, W, B, mode, Cout, Cin)
-        assert (got4 - ref).abs().max().item() < 1e-4, ('f4', case, dil, H, W, B, mode, Cout, Cin)
+        assert (got4 - ref).abs().max().item() < 3e-5, ('f4', case, dil, H, W, B, mode, Cout, Cin)
         assert bool(torch.isnan(out4[..., :4]).all()) and bool(torch.isnan(out4[..., 4 + co:]).all()), ('f4', case)
     _lib.load().l3c_conv_wino4_set_tiles_per_block(0)
 
@@ -399,7 +399,8 @@ WINO4_CASES = WINO_CASES + [
 @pytest.mark.parametrize('dil,Cin,Cout,B,H,W,relu,res,shuffle', WINO4_CASES)
 def test_winograd_f4_conv_vs_fp64_and_f2(dil, Cin, Cout, B, H, W, relu, res, shuffle):
     """Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32 against an fp64 reference and the F(2x2,3x3) kernel.  The transform constants
-    (up to 8 in A^T, 5 in B^T) cost accuracy: unit-scale data stay within 1e-4 of fp64 here (measured ~2e-5; F(2x2): 3e-6);
+    (up to 8 in A^T, 5 in B^T) cost accuracy: unit-scale data stay within 3e-5 of fp64 here (measured 1.3e-5 .. 2e-5 with the points {0, 1, -1, 1/2, -2, inf}; F(2x2): 3e-6;
+    the round-3 gate of 1e-4 was five times the measurement);
     what the L3C forward keeps of north_star's 1e-5 is measured at full size in tests/test_gpu_headline.py.  Determinism and
     batch invariance are exact."""
     from l3c_pytorch_amd import ops
@@ -424,7 +425,7 @@ def test_winograd_f4_conv_vs_fp64_and_f2(dil, Cin, Cout, B, H, W, relu, res, shu
     assert got.shape == ref.shape
     err = (got.double() - ref).abs().max().item()
     print('F(4x4,3x3) max |err| vs fp64: {:.3g}'.format(err))
-    assert err < 1e-4, err
+    assert err < 3e-5, err
     again = ops.conv(_nhwc(x).cuda(), layer, impl='wino4', **kw).cpu().permute(0, 3, 1, 2)
     assert torch.equal(got, again)
     if B > 1:
@@ -447,7 +448,7 @@ def test_winograd_f4_channel_slices_and_tiles_per_block():
     xd = _nhwc(x).cuda()
     cat = torch.zeros(B, H, W, 192, device='cuda')
     ops.conv(xd, layer, out=cat, out_coff=64, impl='wino4')
-    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2).double() - ref).abs().max() < 1e-4
+    assert (cat[..., 64:128].cpu().permute(0, 3, 1, 2).double() - ref).abs().max() < 3e-5
     assert float(cat[..., :64].abs().max()) == 0 and float(cat[..., 128:].abs().max()) == 0
     lib = _lib.load()
     outs = []
@@ -465,7 +466,7 @@ def test_winograd_f4_channel_slices_and_tiles_per_block():
 @pytest.mark.parametrize('B,H,W,Cout', [(1, 32, 32, 64), (2, 46, 70, 64), (1, 128, 192, 64), (3, 8, 6, 64), (1, 2, 2, 64), (2, 64, 96, 120)])
 def test_conv5x5_stride2_polyphase_vs_implicit_gemm_and_fp64(B, H, W, Cout):
     """5x5 stride 2 padding 2 as four 3x3 polyphase convolutions on the F(4x4,3x3) kernel (l3c_conv_wino4_phase, accumulated in
-    place) against the implicit-GEMM 5x5 kernel and fp64: within 1e-4 for unit-scale data; deterministic; output into a channel
+    place) against the implicit-GEMM 5x5 kernel and fp64: within 5e-5 for unit-scale data; deterministic; output into a channel
     slice of a wider NaN-poisoned tensor."""
     from l3c_pytorch_amd import ops
     g = torch.Generator().manual_seed(H * 7 + W)
@@ -479,12 +480,12 @@ def test_conv5x5_stride2_polyphase_vs_implicit_gemm_and_fp64(B, H, W, Cout):
     assert got.shape == ref.shape
     err = (got.double() - ref).abs().max().item()
     print('polyphase 5x5 s2 max |err| vs fp64: {:.3g}'.format(err))
-    assert err < 1e-4, err
+    assert err < 5e-5, err
     gemm = ops.conv(xd, layer, impl='gemm').cpu().permute(0, 3, 1, 2)
     assert (gemm.double() - ref).abs().max().item() < 3e-5
     assert torch.equal(ops.conv(xd, layer, impl='poly5').cpu().permute(0, 3, 1, 2), got)
     x4 = ops.conv(xd, layer, impl='poly5x4').cpu().permute(0, 3, 1, 2)     # the four-launch form (accumulated in place)
-    assert (x4.double() - ref).abs().max().item() < 1e-4
+    assert (x4.double() - ref).abs().max().item() < 5e-5
     wide = torch.full((B, H // 2, W // 2, Cout + 8), float('nan'), device='cuda')
     ops.conv(xd, layer, out=wide, out_coff=4, impl='poly5')
     assert torch.equal(wide[..., 4:4 + Cout].cpu().permute(0, 3, 1, 2), got)

@@ -104,6 +104,18 @@ def _group_errs(P, ref, num_params):
 # within 6.6e-6 (F(2x2,3x3), round 2: 1.1e-6 / 1.9e-6).  The two sides sum ~40 layers of 576-term dot products in different
 # orders and through different transforms (Winograd on MFMA k-blocks vs the CPU's direct convolution).
 TOL_REL = 1e-5
+# ... and, for every parameter group whose values stay below 16 (logit pi, log sigma, lambda, the bottleneck scales' mu: SURVEY.md section 8c
+# P2 "1e-5 (abs, fp32)"), north_star's 1e-5 in ABSOLUTE form as well (round-3 verdict: measured 9.5e-6 on log sigma ~ 9 = 10 ulp; the relative
+# form alone would let a 10x regression of these groups pass).  Only the RGB means (up to ~265, one ulp = 3e-5) keep the relative form alone.
+TOL_ABS = 1e-5
+ABS_GROUP_MAX = 16.0
+
+
+def group_ok(g):
+    """the gate of one parameter group (shared with bench.py's parity leg, which restates it)"""
+    if g['max_value'] <= ABS_GROUP_MAX:
+        return g['max_abs'] < TOL_ABS
+    return g['max_rel'] < TOL_REL
 
 
 def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c, calibrated):
@@ -151,7 +163,7 @@ def test_decoder_side_and_P_vs_oracle_at_768x512(oracle_out, blueprint):
         assert fr < TOL_REL, (s, fa, fr)
         assert pr < TOL_REL, (s, pa, pr)
         for name, g in groups.items():
-            assert g['max_abs'] < TOL_REL * max(g['max_value'], 1.0), (s, name, g)
+            assert group_ok(g), (s, name, g)
 
 
 def test_forward_P_equals_get_P_on_own_bottlenecks_at_768x512(hip_out, blueprint):
