@@ -54,7 +54,7 @@ RGB_SHARED_FLOP_PER_PX = 869168    # RGB Shared with auto_
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--gpus', type=int, default=None, help='ranks = GPUs (default: the launcher\'s WORLD_SIZE, else 1)')
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--config', choices=('headline', 'dataset', 'large'), default='headline')
@@ -75,6 +75,8 @@ def parse_args(argv=None):
     ap.add_argument('--stub-step', action='store_true',
                     help='tests only: no GPU, gloo, a sleep instead of the hot path -- exercises the launch / barrier / max-over-ranks / JSON path')
     a = ap.parse_args(argv)
+    if a.gpus is None:      # under torch.distributed.run without --gpus: the launcher's world size is the truth
+        a.gpus = int(os.environ.get('WORLD_SIZE', '1')) if 'RANK' in os.environ else 1
     defaults = {'headline': (6, 2), 'dataset': (1, 1), 'large': (4, 1)}[a.config]
     a.steps = defaults[0] if a.steps is None else a.steps
     a.warmup = defaults[1] if a.warmup is None else a.warmup
@@ -120,6 +122,27 @@ class Ranks(object):
             else:
                 dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.device)   # RCCL
             self.dist = dist
+
+        # several ranks on ONE host: every rank takes its share of the host's threads / page-locked memory (helpers/sharding.host_budget)
+        from l3c_pytorch_amd.helpers import sharding
+        self.budget = sharding.host_budget(self.world)
+        if self.world > 1:
+            torch.set_num_threads(self.budget['torch_threads'])
+        self._desc = self._describe()       # (a collective: every rank, here; rank 0 prints it)
+
+    def describe(self):
+        return self._desc
+
+    def _describe(self):
+        """what a SCALE record needs to show that N ranks really ran on N devices: visible devices, the rank -> device map, the
+        process-group backend, the per-rank host budget"""
+        devs = [self.local_rank if not self.stub else None]
+        if self.distributed:
+            got = [None] * self.world
+            self.dist.all_gather_object(got, (self.rank, self.local_rank if not self.stub else None))
+            devs = [d for _, d in sorted(got)]
+        return {'world_size': self.world, 'visible_devices': 0 if self.stub else torch.cuda.device_count(), 'rank_to_device': devs,
+                'backend': (self.dist.get_backend() if self.distributed else None), 'host_budget_per_rank': self.budget}
 
     def sync(self):
         if not self.stub:
@@ -169,7 +192,8 @@ def timed(ranks, step, steps, warmup, before_timed=None):
 def contract(args, ranks, value, elapsed, **extra):
     d = {'metric': 'MPix/s encode (net+CDF+AC) on 768x512 RGB', 'value': round(value, 3), 'unit': 'MPix/s',
          'n_gpus': ranks.world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic'}
+         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+         'ranks': ranks.describe()}
     d.update(extra)
     return d
 
@@ -177,7 +201,7 @@ def contract(args, ranks, value, elapsed, **extra):
 # ---- headline: batches of 768x512 ------------------------------------------------------------------------------------------------
 
 
-PMC_TABLE = os.path.join('profiles', 'r03_pmc_bench.json')
+PMC_TABLE = os.path.join('profiles', 'r04_pmc_bench.json')
 
 
 def load_json(rel):
@@ -253,18 +277,39 @@ def roofline_leg(records, args, elapsed):
     pmc, state = load_pmc_table()
     roof['pmc_table'] = {'file': PMC_TABLE, 'state': state, 'csrc_stamp': csrc_stamp()}
     if pmc and state == 'current' and pmc.get('batch') == args.batch:    # counters taken on OTHER kernel sources are not reported
-        k = pmc.get('kernels', {}).get(dom)
-        if k and 'hbm_bytes_per_launch' in k:
+        # Counter evidence must describe the SAME launch population as the algorithmic bytes (round-3 verdict: the round-3 table mixed
+        # in the decode leg's batch-1 launches and showed the 1x1 kernel BELOW its compulsory bytes): per kernel the table must hold
+        # exactly (its steps) x (this run's launches per step) launches, its average duration must agree with the HIP events, and its
+        # bytes must not be below the compulsory (algorithmic) bytes.  Anything else is reported as invalid, not as traffic.
+        checks = {}
+        for kk, vv in pmc.get('kernels', {}).items():
+            if kk not in roof['per_kernel'] or 'hbm_bytes_per_launch' not in vv:
+                continue
+            mine = roof['per_kernel'][kk]
+            algo = mine['algorithmic_gb_per_launch'] * 1e9
+            c = {'launches_match': vv.get('launches_per_step') == mine['launches_per_step'],
+                 'not_below_compulsory': vv['hbm_bytes_per_launch'] >= 0.98 * algo,
+                 'pmc_over_algorithmic': round(vv['hbm_bytes_per_launch'] / algo, 3)}
+            ev_us = by[kk][1] / by[kk][2] * 1e6
+            if 'avg_launch_us_profiled' in vv:
+                c['pmc_over_event_duration'] = round(vv['avg_launch_us_profiled'] / ev_us, 3)
+            checks[kk] = c
+            if c['launches_match'] and c['not_below_compulsory']:
+                mine['pmc_hbm_gb_per_launch'] = round(vv['hbm_bytes_per_launch'] / 1e9, 3)
+                if 'per_variant' in vv:
+                    mine['pmc_hbm_gb_per_launch_by_variant'] = {v: round(x['hbm_bytes_per_launch'] / 1e9, 3) for v, x in vv['per_variant'].items()}
+        roof['pmc_table']['checks'] = checks
+        k, c = pmc.get('kernels', {}).get(dom), checks.get(dom)
+        if k and c and c['launches_match'] and c['not_below_compulsory']:
             roof['traffic'] = int(k['hbm_bytes_per_launch'])
-            roof['traffic_note'] = ('PMC, rocprofv3 passes over this script ({}, same kernel sources): FETCH_SIZE + WRITE_SIZE per '
-                                    'launch, averaged over the kernel\'s launches of a step; = {:.3f} x the algorithmic bytes'.format(
-                                        PMC_TABLE, k['hbm_bytes_per_launch'] / (nbytes / n)))
+            roof['traffic_note'] = ('PMC, rocprofv3 passes over this script with --no-decode ({}, same kernel sources): FETCH_SIZE (x2, gfx950) + '
+                                    'WRITE_SIZE per launch over exactly the launches of {} timed steps ({} per step); = {:.3f} x the algorithmic '
+                                    'bytes'.format(PMC_TABLE, pmc.get('steps'), k.get('launches_per_step'), k['hbm_bytes_per_launch'] / (nbytes / n)))
             for name in ('mfma_busy_frac', 'effective_clock_ghz'):
                 if name in k:
                     roof['pmc_' + name] = k[name]
-            for kk, vv in pmc.get('kernels', {}).items():
-                if kk in roof['per_kernel'] and 'hbm_bytes_per_launch' in vv:
-                    roof['per_kernel'][kk]['pmc_hbm_gb_per_launch'] = round(vv['hbm_bytes_per_launch'] / 1e9, 3)
+        elif k:
+            roof['pmc_table']['state'] = 'invalid'
         if pmc.get('decode_kernels'):
             roof['decode_kernels'] = pmc['decode_kernels']
     return roof
@@ -273,24 +318,37 @@ def roofline_leg(records, args, elapsed):
 def parity_leg(bp, bc, imgs, enc, sd, oracle_file):
     """Image 0 of the batch against the oracle (the checker): P through get_P on the oracle's bottlenecks, symbols of the
     forward pass, the share of RGB symbols coded at the probability floor, and the size of its `.l3c` file against the oracle's
-    (when the CPU baseline leg produced one).  Tolerances in RELATIVE form: |P - P_oracle| <= 1e-5 x the largest |P| of the
-    scale (an absolute 1e-5 is below one ulp for a mean near 255); file within 64 B + 1e-4 of the oracle's."""
+    (when the CPU baseline leg produced one).  P is gated per parameter group like the tests (tests/parity_gate.py)."""
     from oracle import net as onet
     from l3c_pytorch_amd import ops
     img0 = imgs[0:1]
     with torch.no_grad():
         ref = onet.forward(img0.float().cpu(), sd)
     out = bp.net(img0.float())
-    res = {'image': 0, 'max_abs_P': [], 'max_rel_P': [], 'max_value_P': [],
+    res = {'image': 0, 'max_abs_P': [], 'max_rel_P': [], 'max_value_P': [], 'P_groups': [],
            'symbol_flips': sum(int((out.S[s + 1].cpu() != ref.S[s + 1]).sum()) for s in range(3)),
            'bottleneck_levels_used': [int(torch.unique(out.S[s + 1]).numel()) for s in range(3)]}
     f_prev = None
+    groups_ok = True
     for s in (2, 1, 0):
         P, f_prev = bp.net.get_P(s, ref.bn[s + 1].cuda(), f_prev)
-        d = (P.cpu().double() - ref.P[s].double()).abs().max()
+        Pd, Rd = P.cpu().double(), ref.P[s].double()
+        d = (Pd - Rd).abs().max()
         res['max_abs_P'].insert(0, float(d))
-        res['max_rel_P'].insert(0, float(d / ref.P[s].double().abs().max()))
+        res['max_rel_P'].insert(0, float(d / Rd.abs().max()))
         res['max_value_P'].insert(0, float(ref.P[s].abs().max()))
+        # per parameter group (channel index = p * C * K + ...; 4 groups on the RGB scale, 3 on the bottleneck scales): the gate of
+        # tests/parity_gate.py, restated -- absolute 1e-5 where the group's values stay within +-16, relative 1e-5 for the RGB means
+        names = ('logit_pi', 'mu', 'log_sigma', 'lambda')[:4 if s == 0 else 3]
+        n = Pd.shape[1] // len(names)
+        g = {}
+        for p, name in enumerate(names):
+            da = float((Pd[:, p * n:(p + 1) * n] - Rd[:, p * n:(p + 1) * n]).abs().max())
+            mv = float(Rd[:, p * n:(p + 1) * n].abs().max())
+            ok = da < 1e-5 if mv <= 16.0 else da / mv < 1e-5
+            g[name] = {'max_abs': da, 'max_value': mv, 'gate': 'abs 1e-5' if mv <= 16.0 else 'rel 1e-5', 'ok': ok}
+            groups_ok = groups_ok and ok
+        res['P_groups'].insert(0, g)
     # share of the RGB symbols the coder sees with a width-1 interval (c_high == c_low + 1: only the `+ l` guard term is left
     # of the probability; a default-init checkpoint has 100 % on R and G), from the HIP head's own uint16 tables
     dm = bp.losses.loss_dmol_rgb
@@ -312,8 +370,9 @@ def parity_leg(bp, bc, imgs, enc, sd, oracle_file):
         res['size_delta'] = len(hip_file) - len(oracle_file)
         res['framing_equal'] = hip_file[:13] == oracle_file[:13]
         size_ok = abs(res['size_delta']) <= 64 + 1e-4 * len(oracle_file)
-    res['tolerance'] = 'max |P - P_oracle| <= 1e-5 x max |P_oracle| per scale (north_star, relative form); file within 64 B + 1e-4 of the oracle\'s'
-    res['ok'] = bool(max(res['max_rel_P']) < 1e-5 and size_ok)
+    res['tolerance'] = ('per parameter group of P (logit pi / mu / log sigma / lambda): |P - P_oracle| <= 1e-5 ABSOLUTE where the group stays within '
+                        '+-16, <= 1e-5 x the group\'s largest magnitude otherwise (RGB means); file within 64 B + 1e-4 of the oracle\'s')
+    res['ok'] = bool(groups_ok and size_ok)
     return res
 
 
@@ -344,6 +403,33 @@ def decode_leg(bc, enc, imgs, compute_stream):
             'note': 'host .l3c bytes -> pixels in HBM; latency-bound: serial chains of {} symbols per RGB channel, the three '
                     'channels pipelined a chunk of pixels apart (18 chunk steps for 16 chunks: x 1.125); the upper bound charges the whole '
                     'one-image decode -- get_P convolutions, bottleneck scales, tables -- to the RGB chain'.format(H * W)}
+
+
+def latency_leg(bp, bc, img1, compute_stream, reps=5):
+    """The reference's actual CLI use case (l3c.py enc / dec of ONE image): seconds from the image in HBM to its `.l3c` bytes on the
+    host, and from those bytes back to pixels in HBM; median of `reps` after a warm-up, outside the timed region."""
+    import statistics
+    enc_s, dec_s = [], []
+    with torch.cuda.stream(compute_stream):
+        for k in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            data = bc.encode_batch(img1, out=bp.net(img1)).to_bytes()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            dec, _ = bc.decode_batch(data)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if k:
+                enc_s.append(t1 - t0)
+                dec_s.append(t2 - t1)
+        lossless = bool(torch.equal(dec.to(torch.uint8), img1.to(torch.uint8)))
+    e, d = statistics.median(enc_s), statistics.median(dec_s)
+    return {'image': '768x512', 'encode_seconds': round(e, 5), 'decode_seconds': round(d, 5), 'encode_mpix_per_s': round(H * W / 1e6 / e, 2),
+            'decode_mpix_per_s': round(H * W / 1e6 / d, 2), 'decode_ns_per_symbol_upper_bound': round(d / (H * W) * 1e9 / 1.125, 1),
+            'file_bytes': len(data[0]), 'lossless': lossless, 'reps': reps,
+            'note': 'one image: image in HBM -> .l3c bytes on the host -> pixels in HBM (median); the serial interval recurrence of the '
+                    'three 393 216-symbol RGB streams sets the encode time, the symbol-by-symbol decode chains the decode time'}
 
 
 def run_headline(args, ranks):
@@ -389,6 +475,9 @@ def run_headline(args, ranks):
         if ranks.world == 1 and not args.no_parity:
             with torch.cuda.stream(compute_stream):
                 parity = parity_leg(bp, bc, imgs_f, bc.encode_batch(imgs_f[0:1]), sd, oracle_file)
+        latency = None
+        if ranks.world == 1 and not args.no_decode:
+            latency = latency_leg(bp, bc, imgs_f[0:1].contiguous(), compute_stream)
         name, ncu, arch = _lib.device_info()
         peak_gb = round(torch.cuda.max_memory_allocated() / 1e9, 1)
         extra = {}
@@ -404,7 +493,7 @@ def run_headline(args, ranks):
             bpsp=round(bits / subpx, 4), flop_per_px=ALGO_FLOP_PER_PX,
             end_to_end_algorithmic_tflops=round(value * 1e6 * ALGO_FLOP_PER_PX / 1e12 / ranks.world, 2),
             device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=peak_gb,
-            roofline=roofline, cpu_baseline=cpu, parity=parity, decode=decode, **extra)
+            roofline=roofline, cpu_baseline=cpu, parity=parity, decode=decode, latency=latency, **extra)
     return result
 
 
@@ -454,12 +543,13 @@ def run_dataset(args, ranks):
     from l3c_pytorch_amd import _lib
     from l3c_pytorch_amd.helpers import dataset_codec, pad, sharding
     sizes = dataset_codec.draw_sizes(args.images)
-    mine = sharding.shard_indices(args.images, ranks.rank, ranks.world)
+    # largest-first greedy assignment on pixel counts (image areas differ 4x: round robin leaves the slowest of 8 ranks 10 % above the mean)
+    mine = sharding.shard_balanced([h * w for h, w in sizes], ranks.rank, ranks.world)
     with single_thread():
         imgs = {i: synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural') for i in mine}     # host uint8
 
     def step():
-        return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch)
+        return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'])
 
     elapsed, (files, n_shapes, n_launches) = timed(ranks, step, args.steps, args.warmup)
     pixels = sum(sizes[i][0] * sizes[i][1] for i in mine)
@@ -481,7 +571,8 @@ def run_dataset(args, ranks):
                                 'assembly on the device, one D2H'.format(args.images),
                     'images': args.images, 'images_on_rank0': len(mine), 'distinct_padded_shapes_on_rank0': n_shapes,
                     'forward_launches_on_rank0': n_launches, 'max_batch': args.max_batch,
-                    'sharding': 'image i -> rank i mod N (helpers/sharding.py), replicas only'},
+                    'sharding': 'largest-first greedy on pixel counts (helpers/sharding.shard_balanced), replicas only',
+                    'pixels_on_rank0_over_mean': round(pixels * ranks.world / tot_px, 4)},
             bpsp=round(tot_bits / (3 * tot_px), 4), megapixels=round(tot_px / 1e6, 1), round_trip_of_2_images='lossless',
             device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     return result
@@ -539,7 +630,40 @@ def run_large(args, ranks):
 # ---- stub (tests): the launch / timing / reduction / JSON path without a GPU --------------------------------------------------------
 
 
+def run_stub_dataset(args, ranks):
+    """--config dataset --stub-step: config 4's host side on any number of gloo ranks -- the REAL size law, the REAL shard plan and
+    the real reductions; the step is a sleep proportional to the rank's pixels and every image 'costs' (2 + index mod 3) bits per
+    sub-pixel, so that the aggregate bpsp has a closed form the test can check."""
+    from l3c_pytorch_amd.helpers import dataset_codec, sharding
+    sizes = dataset_codec.draw_sizes(args.images)
+    costs = [h * w for h, w in sizes]
+    mine = sharding.shard_balanced(costs, ranks.rank, ranks.world)
+    pixels = sum(costs[i] for i in mine)
+    bits = sum(3 * costs[i] * (2 + i % 3) for i in mine)
+
+    def step():
+        time.sleep(pixels * 1e-9)          # 1 ns per pixel
+        return None
+
+    elapsed, _ = timed(ranks, step, args.steps, args.warmup)
+    tot_px, tot_bits = ranks.sum_over_ranks([pixels, bits])
+    shards = [None] * ranks.world
+    if ranks.distributed:
+        ranks.dist.all_gather_object(shards, {'rank': ranks.rank, 'items': mine, 'pixels': pixels})
+    else:
+        shards = [{'rank': 0, 'items': mine, 'pixels': pixels}]
+    if ranks.rank != 0:
+        return None
+    return contract(args, ranks, tot_px * args.steps / 1e6 / elapsed, elapsed, data='stub (no GPU work)',
+                    bpsp=tot_bits / (3 * tot_px), megapixels=round(tot_px / 1e6, 3),
+                    config={'workload': 'stub dataset step: sleep 1 ns per pixel of the rank\'s shard', 'images': args.images,
+                            'sharding': 'largest-first greedy on pixel counts (helpers/sharding.shard_balanced)', 'shards': shards,
+                            'max_rank_pixels_over_mean': round(max(s['pixels'] for s in shards) * ranks.world / tot_px, 5)})
+
+
 def run_stub(args, ranks):
+    if args.config == 'dataset':
+        return run_stub_dataset(args, ranks)
     from l3c_pytorch_amd.helpers import sharding
     mine = sharding.shard_indices(4 * ranks.world + 1, ranks.rank, ranks.world)      # uneven on purpose
 

@@ -10,9 +10,8 @@ class CodingCDFNonshared(object):
         """l: predicted distribution (N,Kp,H,W); dmll: the DiscretizedMixLogisticLoss of this scale."""
         self.l = l
         self.dmll = dmll
-        # bin edges: torch.linspace on purpose, its rounding is part of the bitstream contract (coders_helpers.py:42-44)
-        self.targets = torch.linspace(dmll.x_min - dmll.bin_width / 2, dmll.x_max + dmll.bin_width / 2, dmll.L + 1,
-                                      dtype=torch.float32, device=l.device)
+        # bin edges (coders_helpers.py:42-44): one definition for every caller, DiscretizedMixLogisticLoss.coding_targets
+        self.targets = dmll.coding_targets(l.device)
         self.total_C = total_C
         self.c_cur = 0
 

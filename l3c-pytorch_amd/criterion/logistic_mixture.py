@@ -55,9 +55,11 @@ class DiscretizedMixLogisticLoss(nn.Module):
         return l.shape[1] // (self._num_params * C)
 
     def coding_targets(self, device='cuda'):
-        """Bin edges the coder evaluates the CDF at (bitcoding/coders_helpers.py:42-44); torch.linspace on purpose."""
+        """Bin edges the coder evaluates the CDF at (bitcoding/coders_helpers.py:42-44); torch.linspace on purpose -- its rounding is
+        part of the bitstream contract, and it is evaluated on the HOST: the device kernel of linspace may round `start + i * step`
+        differently, and the oracle (oracle/cdf.py:coding_targets) is the CPU form (tests/test_gpu_head.py pins the bits)."""
         return torch.linspace(self.x_min - self.bin_width / 2, self.x_max + self.bin_width / 2, self.L + 1,
-                              dtype=torch.float32, device=device)
+                              dtype=torch.float32).to(device)
 
     def cdf_step_non_shared(self, l, targets, c_cur, C, x_c=None):
         """-> CDFOut(pi softmaxed, mu (lambda-coupled), log_sigma clamped, K, targets), each parameter (N,K,H,W)."""

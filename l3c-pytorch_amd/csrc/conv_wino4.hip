@@ -72,6 +72,7 @@ struct Wino4Params {
     W4Div div_groups, div_groups_x, div_chunks;
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
     int tpb, groups_x;
+    unsigned long long *dbg;   // development (-DL3C_W4_TIMELINE): per-wavefront s_memtime stamps, nullptr otherwise
 };
 
 constexpr int OT = 16;                          // output tile of a block: 4 x 4 Winograd tiles of 4 x 4 pixels
@@ -123,7 +124,8 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // patch fetch, 1 no input transform, 2 no weight loads inside the loop, 3 no chunk barrier, 4 no output transform / stores (one
 // store per tile keeps the accumulators alive), 5 no patch stores to LDS, 6 no MFMA (one v_add in its place: the data-movement
 // skeleton alone), 7 all weight loads from the same 4 KB (L1 hits: the instruction stream without the L2 traffic), 8 the input addressed
-// as [C/8][H][W][8], 9 every block fetches the same patch pixels (the fetch instructions without their HBM / L2 latency).  Never defined in the product build.
+// as [C/8][H][W][8], 9 every block fetches the same patch pixels (the fetch instructions without their HBM / L2 latency), 10 half the weight
+// loads (what a kernel with 32 tiles per weight fragment would issue).  Never defined in the product build.
 #ifndef L3C_W4_PROBE
 #define L3C_W4_PROBE 0
 #endif
@@ -255,6 +257,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const int u_lane = (wave * 64 + lane) * 16;
     f32x4 b_ring[L3C_W4_RING];
     auto fetch_b = [&](int cc, int pp) {
+        if constexpr (L3C_W4_PROBE & 1024) {   // timing only: HALF the weight stream (every other pair's fragment is not loaded)
+            if (pp & 1) return f32x4{1.f, 2.f, 3.f, 4.f};
+        }
         if constexpr (L3C_W4_PROBE & 128) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (pp & 3) * (4 * 64 * 16), 0));
         return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, u_lane, (cc * NPP + pp) * (4 * 64 * 16), 0));
     };
@@ -283,6 +288,21 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         const_cast<float *>(RES ? p.res + (((size_t)b * p.Ho + py + dil * sy0) * p.Wo + px) * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias),
         0, RES ? OOB : 0, 0x00020000);
 
+#ifdef L3C_W4_TIMELINE
+    // stamps of wavefront (block, wave) at dbg[((block * 4 + wave) * 16) + k]: 0 start, 1 prologue done, then per tile (2 + 2 t) loop done,
+    // (3 + 2 t) output transform done; 15 = number of tiles.  s_memtime ticks = shader cycles.  Blocks beyond the buffer are not recorded.
+    unsigned long long *dbg_w = (p.dbg && blockIdx.x < 8192) ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+    auto stamp = [&](int k) {
+        if (dbg_w && k < 15) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) dbg_w[k] = t;
+        }
+    };
+    stamp(0);
+    if (dbg_w && lane == 0) dbg_w[15] = (unsigned long long)n_t;
+#else
+    auto stamp = [](int) {};
+#endif
     auto body = [&](auto th_c) __attribute__((always_inline)) {
         constexpr int TH = decltype(th_c)::value;
         float T[3][6];    // rows xi = 3 TH .. 3 TH + 2 of B^T d for this thread's (tile, channel)
@@ -379,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         a_ring[0] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane);
         a_ring[1] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane + VPP);
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): nothing of the prologue stays in flight (see conv_wino.hip)
+        stamp(1);
 
         // Chunk g (buffer parity par = g & 1) -- invariants at its start: V[par] complete and visible; raw[par ^ 1] = patch of
         // chunk g + 1, visible; `stage` = patch of chunk g + 2 (in flight); a_ring = A of pairs 0, 1; the prefetch pointer is at chunk
@@ -479,6 +500,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 chunk(cc + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
             }
             chunk(n_cc - 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
+            stamp(2 + 2 * t);
 
             // ---- output transform Y = A^T M A, in registers: lane (q = lane >> 4, n = lane & 15) holds, in register r of the 36
             // fragments, the transformed tile (ty, tx) = (q, r) of output channel n.  The results leave through a small
@@ -571,6 +593,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 }
             }
             flush(15);
+            stamp(3 + 2 * t);
         }
     };
     if (t_h == 0) body(std::integral_constant<int, 0>{});
@@ -609,6 +632,11 @@ __global__ __launch_bounds__(256) void pack_wino4_kernel(const float *__restrict
 
 static std::atomic<int> g_w4_tpb{getenv("L3C_WINO4_TPB") ? atoi(getenv("L3C_WINO4_TPB")) : 0};
 static const long long g_w4_min_blocks = getenv("L3C_WINO4_MIN_BLOCKS") ? atoll(getenv("L3C_WINO4_MIN_BLOCKS")) : 8 * 512;
+
+#ifdef L3C_W4_TIMELINE
+static unsigned long long *g_w4_dbg = nullptr;
+extern "C" void l3c_conv_wino4_set_debug(void *ptr) { g_w4_dbg = (unsigned long long *)ptr; }
+#endif
 
 extern "C" {
 
@@ -705,6 +733,9 @@ static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int 
     L3C_REQUIRE(S2 * 20 * p.dil * (p.W + 64 * p.dil) * p.out_cstride * 4 < 0x7ffffff0ll && 20ll * p.dil * (p.W + 64 * p.dil) * p.res_cstride * 4 < 0x7ffffff0ll,
                 "image too wide for 32-bit offsets inside a tile row");
     p.total_blocks = (int)total;
+#ifdef L3C_W4_TIMELINE
+    p.dbg = g_w4_dbg;
+#endif
     p.div_groups = w4_div((unsigned)(p.groups_x * p.tiles_y));
     p.div_groups_x = w4_div((unsigned)p.groups_x);
     p.div_chunks = w4_div((unsigned)p.n_chunks_o);

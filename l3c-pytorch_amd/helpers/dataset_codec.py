@@ -68,9 +68,10 @@ def plan_set(shapes, order, max_batch, fac):
     return chunks, padded, pads, len(groups)
 
 
-def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None):
+def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8):
     """imgs: {index: uint8 (3,H,W) HOST tensor}; order: the indices to code.  -> ({index: `.l3c` bytes}, number of distinct
-    padded shapes, number of forward passes).  `marks` (dict) receives host time stamps of the stages.
+    padded shapes, number of forward passes).  `marks` (dict) receives host time stamps of the stages.  n_pinned: page-locked staging
+    buffers of this process (helpers/sharding.host_budget: fewer per rank when several ranks share a host).
 
     The host never waits for the GPU between images and the GPU never for the host [measured on 500 images, profiles/
     r03_dataset_stages.log: padding on the host, pageable H2D copies and one D2H + slicing at the end were 48 % of the wall time, all of it
@@ -92,11 +93,16 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None):
         if marks is not None:
             marks[name] = time.perf_counter()
 
+    for i in order:   # the staging memcpy reinterprets the image's bytes: anything but host uint8 CHW would be silently cast / wrapped
+        t = imgs[i]
+        if t.dtype != torch.uint8 or t.is_cuda or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous():
+            raise ValueError('encode_set: image {} must be a contiguous host uint8 (3,H,W) tensor, got {} {} on {}'.format(
+                i, t.dtype, tuple(t.shape), t.device))
     chunks, padded, pads, n_shapes = plan_set({i: tuple(imgs[i].shape[-2:]) for i in order}, order, max_batch, fac)
     mark('plan (host)')
     ring = getattr(bc, '_h2d_ring', None)
     if ring is None:
-        ring = bc._h2d_ring = _PinnedRing()
+        ring = bc._h2d_ring = _PinnedRing(n_pinned)
     files = {}
     spent = collections.defaultdict(float)       # host seconds per activity (marks['host seconds'])
 

@@ -19,10 +19,10 @@ def _free_port():
     return p
 
 
-def _run(nproc, steps=3, warmup=1):
+def _run(nproc, steps=3, warmup=1, extra=(), gpus_flag=True):
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(nproc), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', str(nproc), '--steps', str(steps),
-           '--warmup', str(warmup), '--stub-step']
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py')] + (['--gpus', str(nproc)] if gpus_flag else []) + [
+           '--steps', str(steps), '--warmup', str(warmup), '--stub-step'] + list(extra)
     env = dict(os.environ, OMP_NUM_THREADS='1')
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
@@ -67,3 +67,40 @@ def test_gpus_flag_must_match_the_launcher():
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--stub-step']
     p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0 and not [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+
+
+def test_launcher_without_gpus_flag_adopts_the_world_size():
+    """`torchrun --nproc-per-node 2 bench.py` (no --gpus): the launcher's WORLD_SIZE is adopted, not rejected (round-3 advice)."""
+    r = _run(2, gpus_flag=False)
+    assert r['n_gpus'] == 2 and r['ranks']['world_size'] == 2 and r['ranks']['backend'] == 'gloo'
+
+
+def test_eight_ranks_share_config_4_evenly():
+    """Multi-GPU readiness without the hardware (round-3 verdict, next 8): EIGHT gloo ranks run `--config dataset --stub-step` over
+    the real size law of config 4 (500 images, areas differing 4x) with the real shard plan: disjoint cover, the slowest rank's
+    pixels within 3 % of the mean (round robin: 10 % over), aggregate bpsp in closed form, the rank -> device record of the JSON
+    line, and a per-rank host budget that shrinks with the world size."""
+    import l3c_pytorch_amd  # noqa: F401
+    from l3c_pytorch_amd.helpers import dataset_codec, sharding
+    r = _run(8, steps=2, warmup=1, extra=['--config', 'dataset', '--images', '500'])
+    assert r['n_gpus'] == 8
+    shards = sorted(r['config']['shards'], key=lambda s: s['rank'])
+    assert [s['rank'] for s in shards] == list(range(8))
+    items = sorted(i for s in shards for i in s['items'])
+    assert items == list(range(500))                                           # disjoint cover
+    sizes = dataset_codec.draw_sizes(500)
+    costs = [h * w for h, w in sizes]
+    for s in shards:
+        assert s['pixels'] == sum(costs[i] for i in s['items'])
+        assert s['items'] == sharding.shard_balanced(costs, s['rank'], 8)       # every rank computed the same plan alone
+    mean = sum(costs) / 8.0
+    assert max(s['pixels'] for s in shards) <= 1.03 * mean
+    assert r['config']['max_rank_pixels_over_mean'] <= 1.03
+    want_bpsp = sum(3 * costs[i] * (2 + i % 3) for i in range(500)) / (3.0 * sum(costs))
+    assert abs(r['bpsp'] - want_bpsp) < 1e-9
+    assert abs(r['megapixels'] - sum(costs) / 1e6) < 1e-3
+    # value = all ranks' pixels / the slowest rank's time
+    assert abs(r['value'] - sum(costs) * 2 / 1e6 / (r['ms_per_step'] * 2 / 1e3)) < 0.02 * r['value']
+    assert r['ranks']['world_size'] == 8 and len(r['ranks']['rank_to_device']) == 8
+    b8, b1 = r['ranks']['host_budget_per_rank'], sharding.host_budget(1, 256)
+    assert b8['pinned_buffers'] < b1['pinned_buffers'] and b8['torch_threads'] * 8 <= max(os.cpu_count(), 8)

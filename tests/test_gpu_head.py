@@ -172,3 +172,21 @@ def test_fused_table_rows_equal_the_two_kernel_table(rgb, C, c):
         part = ops.dmll_cdf_table(P, sym if rgb else None, targets, C, K, rgb, c, p0, n, f)
         assert torch.equal(part[..., :-1], full[:, p0:p0 + n, :-1]), (p0, n)
         assert int(f.item()) == int(flag.item())
+
+
+@pytest.mark.parametrize('x_min,x_max,L', [(0, 255, 256), (-1, 1, 25)])
+def test_coding_targets_on_the_device_are_the_oracles_bits(x_min, x_max, L):
+    """SURVEY section 8 row a10 (bitcoding/coders_helpers.py:42-44): the bin edges the HIP head evaluates the CDF at are bit for
+    bit the oracle's -- for the RGB scale (L = 256) and the bottleneck scales (L = 25) -- on the device, and through the
+    reference-API iterator CodingCDFNonshared as well."""
+    from oracle import cdf as ocdf
+    from l3c_pytorch_amd.bitcoding.coders_helpers import CodingCDFNonshared
+    from l3c_pytorch_amd.criterion.logistic_mixture import DiscretizedMixLogisticLoss
+    dmll = DiscretizedMixLogisticLoss(rgb_scale=(L == 256), x_min=x_min, x_max=x_max, L=L)
+    want = ocdf.coding_targets(x_min, x_max, L)
+    got = dmll.coding_targets('cuda')
+    assert got.is_cuda and got.dtype == torch.float32 and got.shape == (L + 1,)
+    assert torch.equal(got.cpu(), want)
+    assert got.cpu().numpy().tobytes() == want.numpy().tobytes()
+    l = torch.zeros(1, 4, 2, 2, device='cuda')
+    assert torch.equal(CodingCDFNonshared(l, 3 if L == 256 else 5, dmll).targets.cpu(), want)

@@ -26,6 +26,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ac as oracle_ac, bitcoding as obc, net as onet  # noqa: E402
+from tests.parity_gate import group_errs as _group_errs, group_ok  # noqa: E402
 
 H, W = 512, 768
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -89,33 +90,12 @@ def _err(got, ref):
     return float(d.max()), float(d.max() / ref.double().abs().max()), float(ref.abs().max())
 
 
-def _group_errs(P, ref, num_params):
-    """per parameter group of P (channel index = p * C * K + ...): max |diff| / max |ref| of the group."""
-    n = P.shape[1] // num_params
-    out = {}
-    for p, name in enumerate(('logit_pi', 'mu', 'log_sigma', 'lambda')[:num_params]):
-        a, r, m = _err(P[:, p * n:(p + 1) * n], ref[:, p * n:(p + 1) * n])
-        out[name] = {'max_abs': a, 'max_rel': r, 'max_value': m}
-    return out
-
-
 # tolerance (DESIGN.md section 4), RELATIVE to the largest magnitude of the tensor / parameter group: north_star's 1e-5.  Measured
 # on this image (profiles/r03_parity_768x512_*.json) with the Winograd F(4x4,3x3) convolutions: P within 3.5e-6, decoder features
 # within 6.6e-6 (F(2x2,3x3), round 2: 1.1e-6 / 1.9e-6).  The two sides sum ~40 layers of 576-term dot products in different
 # orders and through different transforms (Winograd on MFMA k-blocks vs the CPU's direct convolution).
 TOL_REL = 1e-5
-# ... and, for every parameter group whose values stay below 16 (logit pi, log sigma, lambda, the bottleneck scales' mu: SURVEY.md section 8c
-# P2 "1e-5 (abs, fp32)"), north_star's 1e-5 in ABSOLUTE form as well (round-3 verdict: measured 9.5e-6 on log sigma ~ 9 = 10 ulp; the relative
-# form alone would let a 10x regression of these groups pass).  Only the RGB means (up to ~265, one ulp = 3e-5) keep the relative form alone.
-TOL_ABS = 1e-5
-ABS_GROUP_MAX = 16.0
-
-
-def group_ok(g):
-    """the gate of one parameter group (shared with bench.py's parity leg, which restates it)"""
-    if g['max_value'] <= ABS_GROUP_MAX:
-        return g['max_abs'] < TOL_ABS
-    return g['max_rel'] < TOL_REL
+# P is gated per parameter group (tests/parity_gate.py): absolute 1e-5 for every group whose values stay within +-16, relative for the RGB means
 
 
 def test_encoder_side_vs_oracle_at_768x512(oracle_out, hip_out, synthetic_l3c, calibrated):

@@ -246,3 +246,31 @@ def test_coder_group_cuts():
         for g in (1, 2, 3, 4, 8, 16, (0.08, 0.31, 0.54, 0.77, 0.92, 1.0)):
             c = coder_group_cuts(n, g)
             assert c == sorted(set(c)) and c[-1] == n and c[0] >= 1
+
+
+def test_balanced_shards_on_the_config_4_size_law():
+    """helpers/sharding.shard_balanced (largest-first greedy on pixel counts): disjoint cover, deterministic, and at 8 ranks the
+    heaviest rank stays within 3 % of the mean where round robin is 10 % over (config 4: 500 images, areas differing 4x)."""
+    from l3c_pytorch_amd.helpers import dataset_codec, sharding
+    sizes = dataset_codec.draw_sizes(500)
+    costs = [h * w for h, w in sizes]
+    for world in (1, 2, 3, 8):
+        shards = [sharding.shard_balanced(costs, r, world) for r in range(world)]
+        assert sorted(i for s in shards for i in s) == list(range(500))
+        assert shards == [sharding.shard_balanced(costs, r, world) for r in range(world)]
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) <= 1.03 * sum(costs) / world, (world, max(loads) * world / sum(costs))
+    rr = [sum(costs[i] for i in sharding.shard_indices(500, r, 8)) for r in range(8)]
+    assert max(rr) > 1.08 * sum(costs) / 8                       # what the balanced plan removes
+    assert sharding.shard_balanced([], 0, 4) == [] and sharding.shard_balanced([5], 3, 4) == [] and sharding.shard_balanced([5], 0, 4) == [0]
+    b = [sharding.host_budget(w, 256) for w in (1, 2, 4, 8)]
+    assert [x['pinned_buffers'] for x in b] == [8, 8, 4, 3] and all(x['torch_threads'] * w <= 256 for x, w in zip(b, (1, 2, 4, 8)))
+
+
+def test_coding_targets_host_bits_equal_the_oracle():
+    """the bin edges of the coder (coders_helpers.py:42-44) are computed on the host like the oracle's: identical bits"""
+    from oracle import cdf as ocdf
+    from l3c_pytorch_amd.criterion.logistic_mixture import DiscretizedMixLogisticLoss
+    for x_min, x_max, L in ((0, 255, 256), (-1, 1, 25)):
+        got = DiscretizedMixLogisticLoss(rgb_scale=(L == 256), x_min=x_min, x_max=x_max, L=L).coding_targets('cpu')
+        assert got.numpy().tobytes() == ocdf.coding_targets(x_min, x_max, L).numpy().tobytes()
