@@ -36,6 +36,7 @@ Prints ONE JSON line (rank 0).  Besides the contract fields it carries (headline
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -338,15 +339,16 @@ def parity_leg(bp, bc, imgs, enc, sd, oracle_file):
         res['max_rel_P'].insert(0, float(d / Rd.abs().max()))
         res['max_value_P'].insert(0, float(ref.P[s].abs().max()))
         # per parameter group (channel index = p * C * K + ...; 4 groups on the RGB scale, 3 on the bottleneck scales): the gate of
-        # tests/parity_gate.py, restated -- absolute 1e-5 where the group's values stay within +-16, relative 1e-5 for the RGB means
+        # tests/parity_gate.py, restated -- |diff| < 1e-5 x max(1, largest |value| of the group / 4): absolute 1e-5 up to 4, 2.5e-6 relative above
         names = ('logit_pi', 'mu', 'log_sigma', 'lambda')[:4 if s == 0 else 3]
         n = Pd.shape[1] // len(names)
         g = {}
         for p, name in enumerate(names):
             da = float((Pd[:, p * n:(p + 1) * n] - Rd[:, p * n:(p + 1) * n]).abs().max())
             mv = float(Rd[:, p * n:(p + 1) * n].abs().max())
-            ok = da < 1e-5 if mv <= 16.0 else da / mv < 1e-5
-            g[name] = {'max_abs': da, 'max_value': mv, 'gate': 'abs 1e-5' if mv <= 16.0 else 'rel 1e-5', 'ok': ok}
+            tol = 1e-5 * max(1.0, mv / 4.0)
+            ok = da < tol
+            g[name] = {'max_abs': da, 'max_value': mv, 'tolerance': tol, 'ulp_of_max_value': round(da / (2.0 ** (math.floor(math.log2(max(mv, 1e-30))) - 23)), 1), 'ok': ok}
             groups_ok = groups_ok and ok
         res['P_groups'].insert(0, g)
     # share of the RGB symbols the coder sees with a width-1 interval (c_high == c_low + 1: only the `+ l` guard term is left
@@ -370,8 +372,8 @@ def parity_leg(bp, bc, imgs, enc, sd, oracle_file):
         res['size_delta'] = len(hip_file) - len(oracle_file)
         res['framing_equal'] = hip_file[:13] == oracle_file[:13]
         size_ok = abs(res['size_delta']) <= 64 + 1e-4 * len(oracle_file)
-    res['tolerance'] = ('per parameter group of P (logit pi / mu / log sigma / lambda): |P - P_oracle| <= 1e-5 ABSOLUTE where the group stays within '
-                        '+-16, <= 1e-5 x the group\'s largest magnitude otherwise (RGB means); file within 64 B + 1e-4 of the oracle\'s')
+    res['tolerance'] = ('per parameter group of P (logit pi / mu / log sigma / lambda): |P - P_oracle| < 1e-5 x max(1, largest |value| of the group / 4) '
+                        '-- absolute 1e-5 up to 4, 2.5e-6 relative above (~21 ulp); file within 64 B + 1e-4 of the oracle\'s')
     res['ok'] = bool(groups_ok and size_ok)
     return res
 
