@@ -510,7 +510,9 @@ class Bitcoding(object):
         D = 1 (small batches): everything on the current stream, (chunks + 2) steps of table + decode.
         D = 2 (16 images or more): the channels stay TWO chunks apart, so the tables of step t + 1 need only the symbols of
         step t - 1 and are built on the current stream WHILE a side stream decodes step t: (chunks + 4) steps of
-        max(table, decode)."""
+        max(table, decode).  [round 4, profiles/r04_decode_isolation_experiments.log: by the kernel trace the tables (0.28-0.32 s per batch
+        of 128) and the decoders (0.29 s) overlap 80 %; confining the decoders to compute units of their own (CU-masked streams, balanced
+        over the XCDs) or launching them on a high-priority stream did not shorten the whole decode and is not in the product]"""
         HW = H * W
         n_chunks = max(1, min(self.RGB_CHUNKS, HW // 4096))
         step = -(-HW // n_chunks)

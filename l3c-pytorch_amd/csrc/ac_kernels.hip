@@ -636,9 +636,14 @@ __global__ __launch_bounds__(64) void ac_decode_const_row_kernel(const uint16_t 
 //     for at its end (lds_row_take).
 //   * DMA windows are 16-byte granules at absolute addresses.  A granule is only requested if it holds at least one byte
 //     of the table (others are redirected to the table's last granule), so the reads never leave the pages of the table.
-template <int NJ>
+// IPB_: KB per ring block.  The wide-alphabet (RGB, Lp = 257) decoder comes in two sizes, picked per launch: 9 KB blocks (17 rows per
+// block, 36.5 KB of LDS per stream: the longest DMA lookahead, for a few streams on an empty machine) and 3 KB blocks (5 rows, 12.5 KB:
+// for large batches, where the table kernel of the next chunk step runs beside the decoders and every KB of LDS a decoder holds
+// keeps table blocks off its CU).  [measured, profiles/r04_decode_isolation_experiments.log: 3 KB blocks 0.622 -> 0.570 s per batch of
+// 128, 0.188 -> 0.199 s for one image]
+template <int NJ, int IPB_ = (NJ == 1 ? 3 : 9)>
 struct RingCfg {
-    static constexpr int IPB = NJ == 1 ? 3 : 9;   // 1 KB DMA instructions per block
+    static constexpr int IPB = IPB_;   // 1 KB DMA instructions per block
     static constexpr int NB = 4;
     static constexpr int BLOCK_BYTES = IPB * 1024;
 };
@@ -716,9 +721,9 @@ struct DecodeArgsPack {
     DecodeArgs part[N];
 };
 
-template <int NJ, bool FAST>
+template <int NJ, bool FAST, int IPB_ = (NJ == 1 ? 3 : 9)>
 __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack pack) {
-    using C = RingCfg<NJ>;
+    using C = RingCfg<NJ, IPB_>;
     const DecodeArgs &a = pack.part[blockIdx.y];
     if ((int64_t)blockIdx.x >= a.n_streams) return;
     const uint16_t *cdf = a.cdf;
@@ -853,14 +858,19 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
     for (int i = 0; i < n_parts; ++i) max_streams = pack.part[i].n_streams > max_streams ? pack.part[i].n_streams : max_streams;
     const dim3 grid((unsigned)max_streams, (unsigned)n_parts), block(64);
     const bool small = pack.part[0].Lp - 1 <= 64;
+    // wide alphabet: the small ring from 48 streams per launch on (a batch of 16 images: the decoders then share the machine with the
+    // table kernel of the next chunk step); the result does not depend on the ring size
+    const bool crowd = max_streams * n_parts >= 48;
     if (fast_pass) {   // streams that leave the fast path (or all, if the table is not validated) mark themselves
         if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1, true>), grid, block, 0, st, pack);
+        else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, true, 3>), grid, block, 0, st, pack);
         else hipLaunchKernelGGL((ac_decode_ring_kernel<4, true>), grid, block, 0, st, pack);
         const int rc = l3c::check_launch("ac_decode_ring_kernel<fast>");
         if (rc != L3C_OK) return rc;
     }
     for (int i = 0; i < n_parts; ++i) pack.part[i].force = fast_pass ? 0 : 1;
     if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1, false>), grid, block, 0, st, pack);
+    else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, false, 3>), grid, block, 0, st, pack);
     else hipLaunchKernelGGL((ac_decode_ring_kernel<4, false>), grid, block, 0, st, pack);
     return l3c::check_launch("ac_decode_ring_kernel<generic>");
 }

@@ -86,9 +86,13 @@ constexpr int V_FLOATS = NPP * VPP;             // 4608
 constexpr int U_CHUNK_FLOATS = NPP * 4 * 64 * 4;   // packed weights of one input chunk x one 64-channel output chunk
 constexpr int V_OFF0 = 0, V_OFF1 = V_FLOATS, RAW_OFF0 = 2 * V_FLOATS, RAW_OFF1 = 2 * V_FLOATS + RAW_FLOATS;
 constexpr int LDS_MAIN_FLOATS = 2 * V_FLOATS + 2 * RAW_FLOATS;
-constexpr int WIN_FLOATS = 4 * 80;              // output window of a wavefront: [4 tile rows][16 pixels + 4 of padding][16 channels]
-constexpr int LDS_FLOATS = LDS_MAIN_FLOATS + 4 * 2 * WIN_FLOATS;
-constexpr int W4_LDS_BYTES = LDS_FLOATS * 4;    // 78 208: two blocks per CU
+constexpr int WIN_ROW_FLOATS = 4 * 4 * 16;      // one output row of the four tiles of a tile column: [4 tile rows q][4 pixels j][16 channels]
+// The output window of a wavefront (up to 4 rows = 4 KB) lives in V[1]: the last chunk of a tile reads V[1] and every wavefront has issued
+// its last read of it before the chunk barrier, the next tile's first chunk transforms into it only after the barrier that ends the
+// output transform -- no LDS of its own (round 3: 10 KB per block for the windows).
+static_assert(4 * 4 * WIN_ROW_FLOATS <= V_FLOATS, "the four wavefronts' windows must fit V[1]");
+constexpr int LDS_FLOATS = LDS_MAIN_FLOATS;
+constexpr int W4_LDS_BYTES = LDS_FLOATS * 4;    // 67 968: two blocks per CU
 constexpr int W4_TPB_MAX = 6;
 constexpr int OOB = 0x7ffffff0;                 // a byte offset beyond every buffer: the access is dropped by the range check
 constexpr int N_PIECES = PW * PW * 2;           // 16-byte pieces of a patch (a pixel's 8 channels = 2 pieces)
@@ -156,6 +160,16 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 #ifndef L3C_W4_FETCH_PP
 #define L3C_W4_FETCH_PP 16
 #endif
+// Output rows of a tile column that leave through the LDS window in ONE round (1, 2 or 4; round 4).  Round 3 handed one row at a time through
+// a double-buffered 1.25 KB window: 16 rounds per tile of (4 ds_write_b32, wait, ds_read_b128, wait, store) whose LDS round trips a
+// wavefront could only cover with the next row's dozen VALU instructions -- the time line (profiles/r04_wino4_timeline_before.log) shows
+// 10 k cycles per tile in the output transform (16 k with a residual) for ~650 VALU instructions.  With 4 rows per round the reads of a
+// round are issued right behind its 16 writes (a wavefront's LDS operations execute in order: the window needs no double buffering) and
+// are consumed after the NEXT tile column's whole first transform stage (~120 VALU instructions): no exposed LDS latency, 4 rounds.
+#ifndef L3C_W4_EPI_ROWS
+#define L3C_W4_EPI_ROWS 4
+#endif
+static_assert(L3C_W4_EPI_ROWS == 1 || L3C_W4_EPI_ROWS == 2 || L3C_W4_EPI_ROWS == 4, "rows per round");
 static_assert(L3C_W4_RING == 4 || L3C_W4_RING == 6, "ring depth");
 // slot of pair q (numbered on into the next chunk) in a chunk of buffer parity par: 18 pairs per chunk = 2 mod 4, 0 mod 6
 __device__ __forceinline__ constexpr int ring_slot(int q, int par) { return L3C_W4_RING == 4 ? ((q + 2 * par) & 3) : q % 6; }
@@ -503,10 +517,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             stamp(2 + 2 * t);
 
             // ---- output transform Y = A^T M A, in registers: lane (q = lane >> 4, n = lane & 15) holds, in register r of the 36
-            // fragments, the transformed tile (ty, tx) = (q, r) of output channel n.  The results leave through a small
+            // fragments, the transformed tile (ty, tx) = (q, r) of output channel n.  The results leave through a
             // wavefront-private LDS window that turns "one channel, 16 pixels per lane" into "four adjacent channels of one pixel
-            // per lane": round (r, i) = output row i of the four tiles (., r) -> 16 pixels x 16 channels: four ds_write_b32, one
-            // ds_read_b128, one 16-byte store (and residual load) per lane -- 16 of each per tile instead of 64 four-byte ones.
+            // per lane": row (r, i) = output row i of the four tiles (., r) -> 16 pixels x 16 channels: four ds_write_b32, one
+            // ds_read_b128, one 16-byte store (and residual load) per lane -- 16 of each per tile instead of 64 four-byte ones;
+            // L3C_W4_EPI_ROWS rows per round.
             // Everything the epilogue derives from the lane index is recomputed per tile (the opaque mask hides the index from the
             // loop-invariant code motion): held across the chunk loop these values would push the accumulators out of the registers.
             const int ln = fresh_tid() & 63;
@@ -522,22 +537,24 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 o_lane = 4 * q2 * row_b + j2 * col_b + (wave * 16 + c4 * 4) * 4;
             if constexpr (RES) r_lane = 4 * q2 * rrow_b + j2 * rcol_b + (wave * 16 + c4 * 4) * 4;
             const int oy_l = py + dil * (sy0 + 4 * q2), ox_l = px + dil * (sx0 + j2);
-            // window: [q][16 + 4 pixels-worth of padding][16 channels]; pixel stride 16 floats, q stride 80 floats (banks 16 q + n)
-            float *win = lds + LDS_MAIN_FLOATS + wave * (2 * WIN_FLOATS);
-            float *w_dst = win + q * 80 + (SHUFFLE ? (n & 3) * 4 + (n >> 2) : n);   // shuffle: channels of one sub-pixel adjacent
-            const float *w_src = win + q2 * 80 + j2 * 16 + c4 * 4;
+            // window of this wavefront, in V[1]: [row of the round][q][j][16 channels] (a 2-way bank conflict on the four-byte writes -- lanes
+            // n and n + 32 q -- costs a ds_write_b32 nothing; the 16-byte reads cover 1 KB contiguously)
+            constexpr int ER = L3C_W4_EPI_ROWS;
+            float *win = lds + V_OFF1 + wave * (ER * WIN_ROW_FLOATS);
+            float *w_dst = win + q * 64 + (SHUFFLE ? (n & 3) * 4 + (n >> 2) : n);   // shuffle: channels of one sub-pixel adjacent
+            const float *w_src = win + q2 * 64 + j2 * 16 + c4 * 4;
             auto lane_off = [&](int base, int r, int i) {
                 const bool ok = lane_ok && oy_l + dil * i < p.Ho && ox_l + dil * 4 * r < p.Wo;
                 return ok ? base : OOB;
             };
             f32x4 resv[L3C_W4_RES_RING];
-            auto res_load = [&](int k) {   // round k = r * 4 + i
+            auto res_load = [&](int k) {   // row k = r * 4 + i
                 if constexpr (RES)
                     resv[k % L3C_W4_RES_RING] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                                                 r_rsrc, lane_off(r_lane, k >> 2, k & 3), (k & 3) * rrow_b + (sx0 + 4 * (k >> 2)) * rcol_b, L3C_W4_RES_AUX));
             };
-            auto flush = [&](int k) {      // round k: window -> registers -> memory
-                f32x4 v = *reinterpret_cast<const f32x4 *>(w_src + (k & 1) * WIN_FLOATS);
+            f32x4 rd[ER];                  // the rows of the last round, read back in the store layout (in flight until `finish`)
+            auto finish_row = [&](int k, f32x4 v) {      // row k: registers -> memory
                 if constexpr (RELU) {   // (fmaxf would first canonicalise the value read from LDS: a second v_max per element)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -557,6 +574,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 asm volatile("s_nop 1");
                 __builtin_amdgcn_sched_barrier(0);
             };
+            auto finish = [&](int round) {               // the ER rows of a round; behind each store the residual of a later row is requested
+#pragma unroll
+                for (int e = 0; e < ER; ++e) {
+                    const int k = round * ER + e;
+                    finish_row(k, rd[e]);
+                    if (k + L3C_W4_RES_RING < 16) res_load(k + L3C_W4_RES_RING);   // (into the register quad this row has just released)
+                }
+            };
             if constexpr (L3C_W4_PROBE & 16) {
                 f32x4 sum = acc[0];
 #pragma unroll
@@ -566,7 +591,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 continue;
             }
 #pragma unroll
-            for (int k = 0; k + 1 < L3C_W4_RES_RING; ++k) res_load(k);
+            for (int k = 0; k < L3C_W4_RES_RING; ++k) res_load(k);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float tcol[4][6];   // t[i][nu] = sum_xi A^T[i][xi] M[xi][nu]
@@ -579,20 +604,33 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const int k = r * 4 + i;
+                    const int k = r * 4 + i, e = i % ER;
                     float y[4];
                     at6(tcol[i][0], tcol[i][1], tcol[i][2], tcol[i][3], tcol[i][4], tcol[i][5], y);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w_dst[(k & 1) * WIN_FLOATS + j * 16] = y[j];
-                    // the window is this wavefront's own: its LDS operations execute in order, no block barrier (the fence keeps
-                    // the compiler from moving the reads of other lanes' values above the writes)
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    if (k >= 1) flush(k - 1);
-                    if (k + L3C_W4_RES_RING - 1 < 16) res_load(k + L3C_W4_RES_RING - 1);   // (into the register quad flush(k - 1) has just released)
+                    for (int j = 0; j < 4; ++j) w_dst[e * WIN_ROW_FLOATS + j * 16] = y[j];
+                    if (e == ER - 1) {
+                        // Order of a round, enforced through the memory operations (the optimiser otherwise sinks the transform arithmetic
+                        // below the stores and waits for the LDS reads right behind their issue): this round's window writes -- which
+                        // need the whole transform of this tile column -- | the PREVIOUS round's rows leave `rd` for memory (their LDS
+                        // reads have had that arithmetic, ~120 VALU instructions, to arrive) | this round's reads are issued into `rd`.
+                        asm volatile("" ::: "memory");
+                        if (k >= ER) finish(k / ER - 1);
+                        // the window is this wavefront's own and its LDS operations execute in order: no block barrier, no double
+                        // buffering (the next round's writes are issued behind these reads); the fences keep the compiler from moving
+                        // the reads of other lanes' values above the writes, and the next writes above the reads
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int e2 = 0; e2 < ER; ++e2) rd[e2] = *reinterpret_cast<const f32x4 *>(w_src + e2 * WIN_ROW_FLOATS);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
-            flush(15);
+            finish(16 / ER - 1);
+            // V[1] goes back to the pipeline: the next tile's first chunk transforms into it (at its pair 13, with no barrier in between)
+            if (t + 1 < n_t) __syncthreads();
             stamp(3 + 2 * t);
         }
     };
