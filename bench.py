@@ -20,18 +20,22 @@ pixels / max-over-ranks time.
 ranks, one per visible GPU (and fails loudly when fewer than N are visible): the driver's plain command works unattended.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries (headline config)
-  roofline      dominant kernel = conv_wino_kernel (Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32): `achieved` = the FLOPs the
-                matrix pipe EXECUTES (16/36 of the direct convolution's) summed over its launches in the timed region / their
+  roofline      dominant kernel = conv_wino4_kernel (Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32): `achieved` = the FLOPs the
+                matrix pipe EXECUTES (36/144 of the direct convolution's) summed over its launches in the timed region / their
                 summed HIP-event durations; `peak` = 157.3 TFLOP/s dense fp32 MFMA at 2.4 GHz; the direct-convolution
-                (algorithmic) rate, the PMC-measured HBM traffic per launch and the counter-based pipe occupancy
-                (profiles/r02_pmc_bench.json) ride along
+                (algorithmic) rate, the HBM side of the same launches, and -- from profiles/r04_pmc_bench.json, PMC passes over THIS
+                script reduced to the launches of its timed steps -- the measured HBM traffic per launch and the counter-based pipe
+                occupancy ride along.  A PMC table whose launch population differs from this run's, or whose bytes are below the
+                compulsory (algorithmic) bytes, is reported as `invalid`, never as `traffic`
   cpu_baseline  the oracle (or, where /root/reference exists, the reference itself) timed on this box's host cores
   parity        image 0 of the batch against the oracle: max |P - P_oracle| per scale (get_P on the oracle's bottlenecks),
                 symbol flips, and the HIP `.l3c` file's size against the oracle's
   decode        the last batch decoded back from its files (outside the timed region), lossless check, batch-1 latency
+  latency       ONE image: image in HBM -> .l3c bytes on the host -> pixels in HBM, seconds (the reference CLI's use case)
+  ranks         world size, visible devices, rank -> device map, process-group backend, per-rank host budget
   worst_case_coder   the same step on the DEFAULT-init checkpoint (R and G streams at the 16-bit probability floor: 2.6x the bitstream
                 volume of the calibrated checkpoint), a short untimed-region run: encode / decode MPix/s, bpsp
-  configs       BASELINE.json configs 4 and 5 in reduced form (100 images of the dataset law; one step of the large-image RGB Shared
+  configs       BASELINE.json configs 4 and 5 in reduced form (200 images of the dataset law; one step of the large-image RGB Shared
                 workload), outside the timed region, so that the driver's default run observes them
 """
 import argparse
@@ -227,7 +231,7 @@ def csrc_stamp():
 
 
 def load_pmc_table():
-    """profiles/r03_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
+    """profiles/r04_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
     --pmc run of THIS script, reduced by tools/pmc_bench.py and stamped with csrc_stamp() of the sources it was taken on.
     -> (table or None, 'current' | 'stale' | 'absent')."""
     try:
@@ -470,7 +474,8 @@ def run_headline(args, ranks):
         if ranks.world == 1 and not args.no_cpu_baseline:
             from oracle import cpu_baseline
             cpu, oracle_file = cpu_baseline.run(sd, imgs[0].cpu())
-            elsewhere = load_json(os.path.join('profiles', 'r03_cpu_reference_build_container_{}.json'.format(args.checkpoint)))
+            elsewhere = (load_json(os.path.join('profiles', 'r04_cpu_reference_build_container_{}.json'.format(args.checkpoint))) or
+                         load_json(os.path.join('profiles', 'r03_cpu_reference_build_container_{}.json'.format(args.checkpoint))))
             if elsewhere:     # the UNMODIFIED reference timed where /root/reference exists (python bench.py --cpu-baseline-only)
                 cpu['reference_measured_elsewhere'] = elsewhere
         parity = None
@@ -528,11 +533,11 @@ def extra_legs(args):
         worst['decode'] = {k: wc['decode'][k] for k in ('value', 'unit', 'seconds', 'lossless', 'batch1_seconds')}
     worst['note'] = ('default-init checkpoint: mixtures near 0 for pixels in 0..255, the R and G streams sit at the 16-bit probability '
                      'floor -- 2.6x the calibrated checkpoint\'s bitstream volume, ~6x a trained model\'s')
-    ds = _sub_bench(['--config', 'dataset', '--images', '100', '--steps', '1', '--warmup', '1', '--checkpoint', args.checkpoint])
+    ds = _sub_bench(['--config', 'dataset', '--images', '200', '--steps', '1', '--warmup', '1', '--checkpoint', args.checkpoint])
     lg = _sub_bench(['--config', 'large', '--steps', '2', '--warmup', '1', '--checkpoint', args.checkpoint])
     keys = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'bpsp', 'megapixels', 'round_trip_of_2_images', 'config')
     return {'worst_case_coder': worst,
-            'configs': {'dataset': dict(pick(ds, keys), reduced='100 of the 500 images of BASELINE.json config 4 (python bench.py --config dataset runs all 500)'),
+            'configs': {'dataset': dict(pick(ds, keys), reduced='200 of the 500 images of BASELINE.json config 4 (python bench.py --config dataset runs all 500; the fill and drain of the host pipeline weigh more on the shorter set)'),
                         'large': dict(pick(lg, keys), reduced='2 steps of BASELINE.json config 5 (python bench.py --config large)')}}
 
 

@@ -497,7 +497,8 @@ class Bitcoding(object):
             ops.ac_decode_chunks(parts[k:k + 8])
         return sym
 
-    RGB_CHUNKS = 16
+    RGB_CHUNKS = 16          # chunks per RGB channel for batches of 16 images and more
+    RGB_CHUNKS_FEW = 32      # ... for a few images: the pipeline's fill (two extra chunk steps) weighs more than a step's launches
 
     def _decode_rgb_pipelined(self, P, targets, payloads, B, C, K, H, W):
         """The RGB scale: channel c's means depend on the decoded values of the channels < c AT THE SAME PIXEL
@@ -514,7 +515,9 @@ class Bitcoding(object):
         of 128) and the decoders (0.29 s) overlap 80 %; confining the decoders to compute units of their own (CU-masked streams, balanced
         over the XCDs) or launching them on a high-priority stream did not shorten the whole decode and is not in the product]"""
         HW = H * W
-        n_chunks = max(1, min(self.RGB_CHUNKS, HW // 4096))
+        # one image: 393 216-symbol chains at ~340 ns per symbol; with c chunks the three channels take (c + 2) / c chain times
+        # (16 chunks: x 1.125, 32: x 1.0625) plus ~60 us of launches per step
+        n_chunks = max(1, min(self.RGB_CHUNKS if B >= 16 else self.RGB_CHUNKS_FEW, HW // 4096))
         step = -(-HW // n_chunks)
         step = -(-step // 64) * 64                       # chunk boundaries on the 64-symbol store blocks
         bounds = [(p0, min(step, HW - p0)) for p0 in range(0, HW, step)]

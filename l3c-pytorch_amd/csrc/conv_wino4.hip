@@ -303,11 +303,13 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
         0, RES ? OOB : 0, 0x00020000);
 
 #ifdef L3C_W4_TIMELINE
-    // stamps of wavefront (block, wave) at dbg[((block * 4 + wave) * 16) + k]: 0 start, 1 prologue done, then per tile (2 + 2 t) loop done,
-    // (3 + 2 t) output transform done; 15 = number of tiles.  s_memtime ticks = shader cycles.  Blocks beyond the buffer are not recorded.
-    unsigned long long *dbg_w = (p.dbg && blockIdx.x < 8192) ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 16 : nullptr;
+    // stamps of wavefront (block, wave) at dbg[((block * 4 + wave) * 32) + k]: 0 start, 1 prologue done, then per tile (2 + 2 t) loop done,
+    // (3 + 2 t) output transform done; 15 = number of tiles; 16 + 2 r / 17 + 2 r: inside the output transform of tile 0, tile column r: window
+    // written (both transform stages done) / previous round stored and this round's reads issued; 24..27: inside the first chunk loop of tile 0
+    // (after chunks 0, 1, 3, 5).  s_memtime ticks = shader cycles.  Blocks beyond the buffer are not recorded.
+    unsigned long long *dbg_w = (p.dbg && blockIdx.x < 8192) ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 32 : nullptr;
     auto stamp = [&](int k) {
-        if (dbg_w && k < 15) {
+        if (dbg_w && k != 15 && k < 32) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (lane == 0) dbg_w[k] = t;
         }
@@ -615,6 +617,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                         // need the whole transform of this tile column -- | the PREVIOUS round's rows leave `rd` for memory (their LDS
                         // reads have had that arithmetic, ~120 VALU instructions, to arrive) | this round's reads are issued into `rd`.
                         asm volatile("" ::: "memory");
+                        if (t == 0) stamp(16 + 2 * r);
                         if (k >= ER) finish(k / ER - 1);
                         // the window is this wavefront's own and its LDS operations execute in order: no block barrier, no double
                         // buffering (the next round's writes are issued behind these reads); the fences keep the compiler from moving
@@ -625,6 +628,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                         for (int e2 = 0; e2 < ER; ++e2) rd[e2] = *reinterpret_cast<const f32x4 *>(w_src + e2 * WIN_ROW_FLOATS);
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
+                        if (t == 0) stamp(17 + 2 * r);
                     }
                 }
             }

@@ -1,15 +1,17 @@
 #!/bin/bash
-# Regenerate every profiles/r03_* evidence file with ONE gpurun call (round-2 verdict: "make the evidence reproducible by command"):
+# Regenerate every profiles/r04_* evidence file (E) with ONE gpurun call (round-2 verdict: "make the evidence reproducible by command"):
 #
 #     /usr/local/graft/bin/gpurun --timeout 2400 -- tools/make_evidence.sh      # on the GPU box: writes gpurun_out/evidence/
-#     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r03_*
+#     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r04_*
 #     /usr/local/graft/bin/gpurun --timeout 900 -- tools/make_evidence.sh --bench-only   # the bench lines only (after host-side changes)
 #
 # Steps on the GPU box: (1) the default bench line (after the PMC passes, so that it carries their table); (2) the 768x512 parity suite (tests/test_gpu_headline.py writes the measured
 # errors); (3) rocprofv3 --kernel-trace --stats over the same bench command; (4) three separate rocprofv3 --pmc passes (FETCH_SIZE /
-# WRITE_SIZE / SQ + GRBM counters; never combined with a trace domain) reduced by tools/pmc_bench.py and stamped with the hash of the
-# kernel sources; (5) the other two configs at full size.
-R=r03
+# WRITE_SIZE / SQ + GRBM counters; never combined with a trace domain) over bench.py WITHOUT its decode / parity / extra legs, so that the
+# profiled process launches exactly (warm-up + steps) identical steps; tools/pmc_bench.py keeps the launches of the timed steps only and
+# stamps the table with the hash of the kernel sources; two more passes over a decode-only command for the decode-side kernels;
+# (5) the other two configs at full size.
+R=r04
 if [ "$1" == "--collect" ]; then
     cd "$(dirname "$0")/.." || exit 1
     E=gpurun_out/evidence
@@ -22,6 +24,7 @@ if [ "$1" == "--collect" ]; then
     cp $E/bench_dataset.json profiles/${R}_bench_dataset.json
     cp $E/bench_large.json profiles/${R}_bench_large.json
     cp $E/pytest_headline.log profiles/${R}_pytest_headline.log
+    [ -f $E/decode_overlap.log ] && cp $E/decode_overlap.log profiles/${R}_decode_overlap.log
     ls -la profiles/${R}_*
     exit 0
 fi
@@ -46,17 +49,22 @@ cp gpurun_out/parity_768x512_*.json $E/
 timeout 600 rocprofv3 --kernel-trace --stats -d $E/stats -o run -- python bench.py $LIGHT > $E/bench_profiled_run.json 2> $E/rocprof_stats.err
 DB=$(find $E/stats -name '*.db' | head -1)
 [ -n "$DB" ] && python tools/rocpd_summary.py "$DB" $E/kernel_stats.csv > $E/kernel_stats.txt
-PMCARGS="--steps 2 --warmup 1 $LIGHT --no-kernel-events"
+PMCARGS="--steps 2 --warmup 1 $LIGHT --no-kernel-events --no-decode"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $E/pmc/fetch -o run --output-format csv -- python bench.py $PMCARGS > /dev/null 2> $E/pmc_fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE -d $E/pmc/write -o run --output-format csv -- python bench.py $PMCARGS > /dev/null 2> $E/pmc_write.err
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
     -d $E/pmc/sq -o run --output-format csv -- python bench.py $PMCARGS > /dev/null 2> $E/pmc_sq.err
-python tools/pmc_bench.py $E/pmc 128 > $E/pmc_bench.json
-cp $E/pmc_bench.json profiles/r03_pmc_bench.json      # (the box's copy: the bench line below then reports it as current)
+# decode side: FETCH / WRITE passes over one batch-128 decode (tools/decode_profile.py), and its kernel trace for the overlap analysis
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d $E/pmcd/fetch -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/pmcd_fetch.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $E/pmcd/write -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/pmcd_write.err
+timeout 300 rocprofv3 --kernel-trace -d $E/dtrace -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/dtrace.err
+python tools/decode_overlap.py $E/dtrace > $E/decode_overlap.log
+python tools/pmc_bench.py $E/pmc 128 --steps 2 --warmup 1 --decode-root $E/pmcd > $E/pmc_bench.json
+cp $E/pmc_bench.json profiles/${R}_pmc_bench.json      # (the box's copy: the bench line below then reports it as current)
 timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err
 timeout 900 python bench.py --config dataset > $E/bench_dataset.json 2> $E/bench_dataset.err
 timeout 600 python bench.py --config large > $E/bench_large.json 2> $E/bench_large.err
 # keep the merge-back small: the raw traces stay on the box
-rm -rf $E/stats $E/pmc
+rm -rf $E/stats $E/pmc $E/pmcd $E/dtrace
 ls -la $E
 tail -c 1500 $E/bench_default.json

@@ -30,7 +30,7 @@ kw = dict(residual=r) if a.res else dict(relu=True)
 for _ in range(3):
     ops.conv(x, layer, impl='wino4', **kw)
 torch.cuda.synchronize()
-dbg = torch.zeros(8192 * 4 * 16, dtype=torch.int64, device='cuda')
+dbg = torch.zeros(8192 * 4 * 32, dtype=torch.int64, device='cuda')
 lib.l3c_conv_wino4_set_debug.argtypes = [ctypes.c_void_p]
 lib.l3c_conv_wino4_set_debug(ctypes.c_void_p(dbg.data_ptr()))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -39,7 +39,7 @@ ops.conv(x, layer, impl='wino4', **kw)
 e1.record()
 torch.cuda.synchronize()
 lib.l3c_conv_wino4_set_debug(None)
-d = dbg.cpu().numpy().reshape(8192, 4, 16)
+d = dbg.cpu().numpy().reshape(8192, 4, 32)
 d = d[d[:, 0, 15] > 0]
 nt = d[:, :, 15]
 pro = (d[:, :, 1] - d[:, :, 0]).astype(np.float64)
@@ -56,3 +56,13 @@ print('cycles per wavefront: prologue {:.0f} | per tile: loop {:.0f} (p10 {:.0f}
     pro.mean(), loop.mean(), np.percentile(loop, 10), np.percentile(loop, 90), epi.mean(), np.percentile(epi, 10), np.percentile(epi, 90)))
 print('first tile of a block: loop {:.0f}, later tiles {:.0f}'.format(loops[0].mean(), np.concatenate(loops[1:]).mean() if len(loops) > 1 and len(loops[1]) else float('nan')))
 print('matrix-pipe time per tile and wavefront 18432 cycles: share of the wavefront\'s life {:.3f}'.format((18432.0 * nt).sum() / life.sum()))
+# inside the output transform of tile 0 (stamps 16..23): per tile column r, cycles from the previous stamp to "window written" (both
+# transform stages of the column: ~120 VALU instructions + 16 LDS writes) and on to "previous round stored, this round's reads issued"
+prev = d[:, :, 2]
+parts = []
+for r in range(4):
+    a, b = d[:, :, 16 + 2 * r], d[:, :, 17 + 2 * r]
+    parts.append('r{}: transform {:.0f} + stores/reads {:.0f}'.format(r, (a - prev).astype(np.float64).mean(), (b - a).astype(np.float64).mean()))
+    prev = b
+parts.append('last round out {:.0f}'.format((d[:, :, 3] - prev).astype(np.float64).mean()))
+print('output transform of tile 0: ' + ' | '.join(parts))
