@@ -166,6 +166,15 @@ __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, floa
 // 10 k cycles per tile in the output transform (16 k with a residual) for ~650 VALU instructions.  With 4 rows per round the reads of a
 // round are issued right behind its 16 writes (a wavefront's LDS operations execute in order: the window needs no double buffering) and
 // are consumed after the NEXT tile column's whole first transform stage (~120 VALU instructions): no exposed LDS latency, 4 rounds.
+// Depth of the A-fragment ring (register quads of V read ahead from LDS): 2 = the pair after the current one, 3 = two pairs ahead.  A
+// wavefront that has the matrix pipe to itself (its SIMD partner in its prologue / output transform, or a launch too small for two
+// blocks per CU) runs a pair in 128 cycles -- about one ds_read_b128 round trip.  NPP % depth must be 0.  [measured, 64->64 at 256x384,
+// batch 1 / 4 / 32: depth 3 = depth 2 to the microsecond (0.036 / 0.105 / 0.746 ms) and spills 1-3 registers: the A reads are not what a
+// lone wavefront waits for; left at 2]
+#ifndef L3C_W4_ARING
+#define L3C_W4_ARING 2
+#endif
+static_assert(L3C_W4_ARING == 2 || L3C_W4_ARING == 3, "A ring depth");
 #ifndef L3C_W4_EPI_ROWS
 #define L3C_W4_EPI_ROWS 4
 #endif
@@ -285,7 +294,9 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
 
     // ---- A fragments: lane (tile m = lane & 15, k group lane >> 4)
     const int a_lane = (lane & 15) * 16 + (lane >> 4) * 4;
-    f32x4 a_ring[2];
+    constexpr int AR = L3C_W4_ARING;
+    static_assert(NPP % AR == 0, "pairs per chunk must be a multiple of the A ring depth");
+    f32x4 a_ring[AR];
 
     f32x4 acc[36];
     const int co_lane = chunk_o * 64 + wave * 16 + (lane & 15);
@@ -305,8 +316,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
 #ifdef L3C_W4_TIMELINE
     // stamps of wavefront (block, wave) at dbg[((block * 4 + wave) * 32) + k]: 0 start, 1 prologue done, then per tile (2 + 2 t) loop done,
     // (3 + 2 t) output transform done; 15 = number of tiles; 16 + 2 r / 17 + 2 r: inside the output transform of tile 0, tile column r: window
-    // written (both transform stages done) / previous round stored and this round's reads issued; 24..27: inside the first chunk loop of tile 0
-    // (after chunks 0, 1, 3, 5).  s_memtime ticks = shader cycles.  Blocks beyond the buffer are not recorded.
+    // written (both transform stages done) / previous round stored and this round's reads issued; 24..27 / 28..31: inside the chunk loops of tiles 0 / 1
+    // (after chunks 0, 2, 4, 6).  s_memtime ticks = shader cycles.  Blocks beyond the buffer are not recorded.
     unsigned long long *dbg_w = (p.dbg && blockIdx.x < 8192) ? p.dbg + ((size_t)blockIdx.x * 4 + wave) * 32 : nullptr;
     auto stamp = [&](int k) {
         if (dbg_w && k != 15 && k < 32) {
@@ -412,8 +423,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             tr_write(lds + V_OFF0 + t_dst, k);
         }
         __syncthreads();
-        a_ring[0] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane);
-        a_ring[1] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane + VPP);
+#pragma unroll
+        for (int j = 0; j < AR; ++j) a_ring[j] = *reinterpret_cast<const f32x4 *>(lds + V_OFF0 + a_lane + j * VPP);
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): nothing of the prologue stays in flight (see conv_wino.hip)
         stamp(1);
 
@@ -449,13 +460,14 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int pp = 0; pp < NPP; ++pp) {
-                const f32x4 &A = a_ring[pp & 1];
+                const f32x4 &A = a_ring[pp % AR];
                 const bool from_burst = !FIRST && pp >= 3 && pp <= 9;
                 const f32x4 &Bv = from_burst ? b_burst[pp >= 3 && pp <= 9 ? pp - 3 : 0] : b_ring[ring_slot(pp, par)];
                 if (pp == NPP - 1) {
                     // everything chunk g + 1 needs from this wave is issued: V[par ^ 1] written, patch g + 2 stored
                     if constexpr (!(L3C_W4_PROBE & 8)) __syncthreads();
-                    a_ring[0] = *reinterpret_cast<const f32x4 *>(a_nxt);
+#pragma unroll
+                    for (int j = 0; j + 1 < AR; ++j) a_ring[j] = *reinterpret_cast<const f32x4 *>(a_nxt + j * VPP);
                 }
                 L3C_W4_MFMA(2 * pp, A[0], Bv[0], true)
                 // one patch column per pair, arithmetic in pairs 7..12 (the burst's registers free up as its pairs 3..9 are consumed), its
@@ -480,8 +492,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 }
                 L3C_W4_MFMA(2 * pp + 1, A[3], Bv[3], false)
                 // (the rings are reloaded behind the pair's last MFMA: A and Bv are references into them)
-                if (pp < NPP - 2) a_ring[pp & 1] = *reinterpret_cast<const f32x4 *>(a_cur + (pp + 2) * VPP);
-                if (pp == NPP - 1) a_ring[1] = *reinterpret_cast<const f32x4 *>(a_nxt + VPP);
+                if (pp + AR < NPP) a_ring[pp % AR] = *reinterpret_cast<const f32x4 *>(a_cur + (pp + AR) * VPP);
+                if (pp == NPP - 1) a_ring[AR - 1] = *reinterpret_cast<const f32x4 *>(a_nxt + (AR - 1) * VPP);
                 // the ring: pair pp + 4 -- of this chunk, or (numbered on) of the next one, whose pairs 3..9 come from the burst
                 if constexpr (LB) {
                     const int nxt = pp + L3C_W4_RING;
@@ -511,9 +523,15 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
                 acc[7][r] = v;
             }
             chunk(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+#ifdef L3C_W4_TIMELINE
+            if (t < 2) stamp(24 + 4 * t);                        // after chunk 0 of tiles 0 and 1
+#endif
             for (int cc = 1; cc + 1 < n_cc; cc += 2) {
                 chunk(cc, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
                 chunk(cc + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+#ifdef L3C_W4_TIMELINE
+                if (t < 2 && cc <= 5) stamp(24 + 4 * t + (cc + 1) / 2);   // after chunks 2, 4, 6
+#endif
             }
             chunk(n_cc - 1, std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{});
             stamp(2 + 2 * t);

@@ -10,7 +10,7 @@ import l3c_pytorch_amd  # noqa: E402,F401
 from l3c_pytorch_amd import ops  # noqa: E402
 
 g = torch.Generator().manual_seed(0)
-B, H, W = 32, 256, 384
+B, H, W = int(os.environ.get('W4_PROBE_B', '32')), 256, 384
 w = torch.randn(64, 64, 3, 3, generator=g) / 24
 b = torch.randn(64, generator=g)
 layer = ops.PackedConv(w, b)
@@ -32,4 +32,4 @@ for name, kw in [('relu', dict(relu=True)), ('res', dict(residual=r))]:
         torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / 10)
     out.append('{} {:.3f} ms'.format(name, best))
-print(os.environ.get('L3C_LIB', 'product').split('_')[-1], ' | '.join(out))
+print(os.environ.get('L3C_LIB', 'product').split('_')[-1], 'B={}'.format(B), ' | '.join(out))

@@ -66,3 +66,13 @@ for r in range(4):
     prev = b
 parts.append('last round out {:.0f}'.format((d[:, :, 3] - prev).astype(np.float64).mean()))
 print('output transform of tile 0: ' + ' | '.join(parts))
+# inside the chunk loops of tile 0 (first of the block, right behind the prologue) and tile 1: cycles for chunk 0, chunks 1-2, 3-4, 5-6, 7
+for t in (0, 1):
+    m = nt[:, 0] > t
+    start = (d[:, :, 1] if t == 0 else d[:, :, 3])[m]
+    marks = [d[:, :, 24 + 4 * t + k][m] for k in range(4)] + [d[:, :, 2 + 2 * t][m]]
+    seg, prev = [], start
+    for x in marks:
+        seg.append((x - prev).astype(np.float64).mean())
+        prev = x
+    print('tile {} loop: chunk 0 {:.0f} | chunks 1-2 {:.0f} | 3-4 {:.0f} | 5-6 {:.0f} | chunk 7 {:.0f}'.format(t, *seg))
