@@ -556,7 +556,8 @@ def run_dataset(args, ranks):
         imgs = {i: synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural') for i in mine}     # host uint8
 
     def step():
-        return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'])
+        return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'],
+                                        canvas=os.environ.get('L3C_CANVAS', '0') != '0')
 
     elapsed, (files, n_shapes, n_launches) = timed(ranks, step, args.steps, args.warmup)
     pixels = sum(sizes[i][0] * sizes[i][1] for i in mine)

@@ -27,7 +27,7 @@ class ConvDesc(ctypes.Structure):
                 ('residual', c_vp), ('res_cstride', c_int), ('res_coff', c_int),
                 ('out', c_vp), ('out_cstride', c_int), ('out_coff', c_int),
                 ('B', c_int), ('Hin', c_int), ('Win', c_int), ('Cin', c_int), ('Cout', c_int),
-                ('KS', c_int), ('stride', c_int), ('dilation', c_int), ('epilogue', c_int)]
+                ('KS', c_int), ('stride', c_int), ('dilation', c_int), ('epilogue', c_int), ('out_dims', c_vp)]
 
 
 class AcGroup(ctypes.Structure):
@@ -88,9 +88,9 @@ PROTOTYPES = {
     'l3c_conv_pw_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_pw': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_direct': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
-    'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
+    'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'l3c_to_q_quantize': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    'l3c_dec_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
+    'l3c_dec_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
     'l3c_meanshift_planar': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'l3c_rgb_to_u8': (c_int, [c_vp, ctypes.POINTER(c_f32), c_i64, c_i64, c_vp, c_vp]),
     'l3c_resample_u8': (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -122,8 +122,8 @@ def load():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.l3c_abi_version() != 1:
-            raise L3CError('ABI version mismatch: library {} != binding 1'.format(lib.l3c_abi_version()))
+        if lib.l3c_abi_version() != 2:
+            raise L3CError('ABI version mismatch: library {} != binding 2'.format(lib.l3c_abi_version()))
         _lib = lib
     return _lib
 

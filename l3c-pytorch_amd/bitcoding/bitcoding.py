@@ -308,6 +308,29 @@ class Bitcoding(object):
             enc.pending.append((C, Hs, Ws, iv))
         return enc
 
+    def prepare_canvas(self, x, dims):
+        """`prepare_batch` for images of DIFFERENT sizes that share one forward pass (MultiscaleNetwork.forward_canvas): x (B,3,Hc,Wc)
+        canvas, image b in its top-left dims[b] = (H_b, W_b) corner, zero elsewhere.  -> one EncodedBatch per image (batch size 1, its own
+        shape), from that image's slices of the canvas-shaped symbols and P: byte for byte the files of the image coded alone."""
+        net = self.blueprint.net
+        sym, P, _ = net.forward_canvas(x.to('cuda', torch.float32), dims)
+        K = net.config_ms.prob.K
+        encs = []
+        for b, (H, W) in enumerate(dims):
+            enc = EncodedBatch(1, (H, W))
+            for scale, dmll, uniform in self.iter_scale_dmll():
+                hs, ws = H >> scale, W >> scale
+                s_b = sym[scale][b:b + 1, :, :hs, :ws].contiguous()
+                C = s_b.shape[1]
+                if uniform:
+                    iv = ops.intervals_from_table(self._uniform_row(dmll.L), s_b.reshape(C, hs * ws), C, hs * ws, broadcast_row=True)
+                else:
+                    P_b = P[scale][b:b + 1, :hs, :ws, :].contiguous()
+                    iv = ops.dmll_encode_intervals(P_b, s_b, self._targets(dmll), C, K, dmll.rgb_scale)
+                enc.pending.append((C, hs, ws, iv))
+            encs.append(enc)
+        return encs
+
     def code(self, batches):
         """Second half: ONE grouped range-coder launch (l3c_ac_encode_groups) over every scale of every prepared batch
         -- all their streams are coded concurrently, whatever the image sizes -- on a side stream that the current
@@ -347,8 +370,9 @@ class Bitcoding(object):
     N_CODER_GROUPS = 4
 
     def encode_many(self, batches, upload=None, on_group=None, n_groups=None, weights=None):
-        """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries -- images of different sizes
-        cannot share a batch).  -> list of EncodedBatch, in the order given.
+        """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries), or -- through `upload` -- entries that turn
+        into (canvas, dims) pairs: images of DIFFERENT sizes sharing one forward pass (prepare_canvas).  -> list, in the order given,
+        of EncodedBatch (a list of one EncodedBatch per image for a canvas entry).
         Small batches leave most of the machine idle (one 768x512 image is 192 tiles at the first scale, 12 at the
         coarsest, for 256 CUs) and their serial coder chains are as long as ever, so
           * the forward passes + heads of different batches run on N_FORWARD_STREAMS streams side by side, largest
@@ -386,26 +410,32 @@ class Bitcoding(object):
         result = [None] * len(batches)
         pending, coded = [], []
 
+        def flat(k):           # an entry's EncodedBatch objects: one, or one per image of a canvas entry
+            return result[k] if isinstance(result[k], list) else [result[k]]
+
         def collect_finished(block):
             # oldest group first; without `block` only groups whose coder launch has COMPLETED (the host must never sit waiting for a
             # latency-bound coder launch while the forward streams run dry)
-            while coded and (block or result[coded[0][0]].done[-1].query()):
+            while coded and (block or flat(coded[0][0])[0].done[-1].query()):
                 self._collect(coded.pop(0), result, on_group)
 
         for n, i in enumerate(order):
             st = fwd[n % len(fwd)]
             with torch.cuda.stream(st):
                 x = batches[i] if upload is None else upload(batches[i])
+                dims = None
+                if isinstance(x, tuple):               # (canvas, [(H_b, W_b)]): images of different sizes in one pass
+                    x, dims = x
                 if x.is_cuda:
                     x.record_stream(st)
-                result[i] = self.prepare_batch(x)
+                result[i] = self.prepare_batch(x) if dims is None else self.prepare_canvas(x, dims)
                 ev = torch.cuda.Event()
                 ev.record(st)
             pending.append((i, ev))
             if n + 1 in cuts:
                 for _, ev in pending:
                     main.wait_event(ev)            # `code` orders its side stream after the current stream
-                self.code([result[k] for k, _ in pending])
+                self.code([e for k, _ in pending for e in flat(k)])
                 if on_group is not None:
                     coded.append([k for k, _ in pending])
                 pending = []
@@ -415,7 +445,8 @@ class Bitcoding(object):
 
     @staticmethod
     def _collect(indices, result, on_group):
-        with torch.cuda.stream(result[indices[0]].coder_stream):
+        first = result[indices[0]][0] if isinstance(result[indices[0]], list) else result[indices[0]]
+        with torch.cuda.stream(first.coder_stream):
             on_group([(k, result[k]) for k in indices])
 
     def decode_batch(self, files):

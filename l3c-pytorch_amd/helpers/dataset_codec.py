@@ -68,7 +68,35 @@ def plan_set(shapes, order, max_batch, fac):
     return chunks, padded, pads, len(groups)
 
 
-def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8):
+def plan_canvases(shapes, order, max_batch, fac, max_waste=0.25):
+    """Host-side plan for passes that may hold images of DIFFERENT padded shapes (MultiscaleNetwork.forward_canvas): the images are
+    sorted by (aspect class, height) and cut greedily into passes of at most max_batch whose canvas -- the bounding box of the pass's
+    padded shapes -- wastes at most max_waste of its area.  Same return value as plan_set; a pass of equal shapes is a plain batch."""
+    pads, padded_of = {}, {}
+    for i in order:
+        h, w = shapes[i]
+        pads[i] = pad.padding_for(h, w, fac)
+        padded_of[i] = (h + pads[i][2] + pads[i][3], w + pads[i][0] + pads[i][1])
+    ranked = sorted(order, key=lambda i: (round(padded_of[i][1] / float(padded_of[i][0]), 1), padded_of[i][0], padded_of[i][1], i))
+    chunks, canvas = [], []
+    cur, ch, cw, area = [], 0, 0, 0
+    for i in ranked:
+        h, w = padded_of[i]
+        nh, nw = max(ch, h), max(cw, w)
+        if cur and (len(cur) >= max_batch or nh * nw * (len(cur) + 1) > (1.0 + max_waste) * (area + h * w)):
+            chunks.append(cur)
+            canvas.append((ch, cw))
+            cur, ch, cw, area = [], 0, 0, 0
+            nh, nw = h, w
+        cur.append(i)
+        ch, cw, area = nh, nw, area + h * w
+    if cur:
+        chunks.append(cur)
+        canvas.append((ch, cw))
+    return chunks, canvas, pads, len(set(padded_of.values())), padded_of
+
+
+def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8, canvas=False, max_waste=0.25):
     """imgs: {index: uint8 (3,H,W) HOST tensor}; order: the indices to code.  -> ({index: `.l3c` bytes}, number of distinct
     padded shapes, number of forward passes).  `marks` (dict) receives host time stamps of the stages.  n_pinned: page-locked staging
     buffers of this process (helpers/sharding.host_budget: fewer per rank when several ranks share a host).
@@ -98,7 +126,16 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
         if t.dtype != torch.uint8 or t.is_cuda or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous():
             raise ValueError('encode_set: image {} must be a contiguous host uint8 (3,H,W) tensor, got {} {} on {}'.format(
                 i, t.dtype, tuple(t.shape), t.device))
-    chunks, padded, pads, n_shapes = plan_set({i: tuple(imgs[i].shape[-2:]) for i in order}, order, max_batch, fac)
+    shapes = {i: tuple(imgs[i].shape[-2:]) for i in order}
+    # canvas: images of different padded shapes share a pass (MultiscaleNetwork.forward_canvas; round 4).  The files are byte-identical and
+    # the passes 3-6x fewer, but it is OFF by default: [measured, profiles/r04_canvas_passes.log] 200 images 117.5 vs 116.7 MPix/s, 500 images
+    # 122.6 vs 146.9 -- with three forward streams the GPU is already > 90 % busy on the small passes, and a canvas pass pays for its empty
+    # margin (13-15 % of the area: fills, the per-pixel layers) and for slicing every image's P out of the canvas
+    if canvas:
+        chunks, padded, pads, n_shapes, padded_of = plan_canvases(shapes, order, max_batch, fac, max_waste)
+    else:
+        chunks, padded, pads, n_shapes = plan_set(shapes, order, max_batch, fac)
+        padded_of = {i: padded[ci] for ci, c in enumerate(chunks) for i in c}
     mark('plan (host)')
     ring = getattr(bc, '_h2d_ring', None)
     if ring is None:
@@ -128,8 +165,10 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
     def to_device(chunk, sizes, Hp, Wp, k, stage):
         dev = stage.cuda(non_blocking=True)
         ring.sent(k)
-        if not any(any(pads[i]) for i in chunk):
+        same = all(padded_of[i] == (Hp, Wp) for i in chunk)
+        if same and not any(any(pads[i]) for i in chunk):
             return dev.view(len(chunk), 3, Hp, Wp)
+        # zero padding of every image AND, for a canvas pass, the zero margin around the smaller images: written on the device
         x = torch.zeros((len(chunk), 3, Hp, Wp), dtype=torch.uint8, device='cuda')
         off = 0
         for b, (i, n) in enumerate(zip(chunk, sizes)):
@@ -137,13 +176,23 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
             left, _, top, _ = pads[i]
             x[b, :, top:top + h, left:left + w] = dev[off:off + n].view(3, h, w)
             off += n
-        return x
+        return x if same else (x, [padded_of[i] for i in chunk])
 
     def on_group(group):
         t0 = time.perf_counter()
-        encs = [enc for _, enc in group]
-        for (ci, _), fs in zip(group, EncodedBatch.many_to_bytes(encs, [[pads[i] for i in chunks[ci]] for ci, _ in group])):
-            for i, f in zip(chunks[ci], fs):
+        encs, pad_lists, owners = [], [], []
+        for ci, enc in group:
+            if isinstance(enc, list):          # a canvas pass: one EncodedBatch (of one image) per image
+                for i, e in zip(chunks[ci], enc):
+                    encs.append(e)
+                    pad_lists.append([pads[i]])
+                    owners.append([i])
+            else:
+                encs.append(enc)
+                pad_lists.append([pads[i] for i in chunks[ci]])
+                owners.append(chunks[ci])
+        for idxs, fs in zip(owners, EncodedBatch.many_to_bytes(encs, pad_lists)):
+            for i, f in zip(idxs, fs):
                 files[i] = f
         spent['collect files (sizes, assembly, D2H, slicing)'] += time.perf_counter() - t0
 
