@@ -52,10 +52,12 @@ int l3c_stream_destroy(l3c_stream_t stream);
 /* ---- arithmetic coder (replaces torchac.cpp) ---------------------------------------------------------------------- */
 
 /*
- * Packed coding interval of one symbol: bits 0..15 = c_low, bits 16..31 = c_high - 1 (c_high in 1..65536).
- * Interval streams are stored in blocks of 64 symbols: word(stream s, symbol t) = iv[((t/64)*n_streams + s)*64 + t%64],
- * so the kernel that writes them and the lane that codes stream s both touch contiguous 256-byte runs.
- * l3c_interval_words(n_streams, n_sym) gives the buffer size in uint32 words.
+ * Coding interval of one symbol: TWO words, one per role of the lane pair that codes the stream (csrc/ac_core.h):
+ * role 0 = c_low, role 1 = 65536 - c_high (c_high in 1..65536).  Interval streams are stored in blocks of 64 symbols,
+ * per block and stream one 64-word run per role: word(stream s, symbol t, role r) = iv[(((t/64)*n_streams + s)*2 + r)*64 + t%64],
+ * so the kernel that writes them and the lane that codes role r of stream s both touch contiguous 256-byte runs.
+ * The buffer is opaque between the l3c_*intervals* call that fills it and the l3c_ac_encode* call that consumes it;
+ * l3c_interval_words(n_streams, n_sym) gives its size in uint32 words.
  */
 int64_t l3c_interval_words(int64_t n_streams, int64_t n_sym);
 
@@ -73,8 +75,9 @@ int l3c_ac_intervals_from_table(const uint16_t *cdf, int64_t row_stride, int Lp,
  * Range-encode n_streams independent symbol streams of equal length.  Bit-exact restatement of encode()
  * (torchac.cpp:152-227): 32-bit low/high, 16-bit precision, pending-bit carry handling, final flush of `pending+1`
  * bits, zero padding to a byte boundary, MSB-first.  Two launches:
- *   phase 1  one stream per lane (64 per wavefront): the serial interval recurrence only; every interval word is
- *            REPLACED IN PLACE by a 28-bit record (top bits of low', prefix length n <= 18, underflow run m)
+ *   phase 1  one stream per lane PAIR (32 per wavefront; one lane updates low, its neighbour ~high, with the same
+ *            ~15 instructions per symbol): the serial interval recurrence only; every interval word is REPLACED IN PLACE
+ *            by the bound right after the interval update (low' / ~high'), from which phase 2 derives what is emitted
  *   phase 2  one stream per wavefront, 64 symbols per step: records -> bits (wave scans + LDS merge), coalesced stores
  * Precondition: c_high > c_low for every symbol (strictly increasing table rows), as for the reference.
  *   intervals  in/out, CLOBBERED

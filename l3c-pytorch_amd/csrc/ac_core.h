@@ -43,7 +43,7 @@ L3C_HD uint32_t ones(int n) {  // n in [0, 32]
     return n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
 }
 
-// Packed interval word (include/l3c_hip.h): c_low | (c_high - 1) << 16.
+// Packed interval word c_low | (c_high - 1) << 16 of the one-lane form (encode_state_step; the kernels use role_word below).
 L3C_HD uint32_t pack_interval(uint32_t c_lo, uint32_t c_hi) { return (c_lo & 0xFFFFu) | ((c_hi - 1u) << 16); }
 L3C_HD uint32_t interval_lo(uint32_t w) { return w & 0xFFFFu; }
 L3C_HD uint32_t interval_hi(uint32_t w) { return (w >> 16) + 1u; }
@@ -260,6 +260,59 @@ L3C_HD uint32_t pack_record(uint32_t rec_lo, uint32_t rec_nm) {
 L3C_HD uint32_t record_n(uint32_t r) { return (r >> 5) & 31u; }
 L3C_HD uint32_t record_m(uint32_t r) { return r & 31u; }
 L3C_HD uint32_t record_top(uint32_t r) { return r >> 10; }
+
+// ---- phase 1 on a lane PAIR: the role-symmetric form of the recurrence (round 4) ------------------------------------------
+// A lone wavefront issues one instruction every ~4 cycles whatever the dependencies, so the chain's cost is its instruction
+// COUNT.  encode_state_step spends ~45 on a symbol: both bounds go through the same multiply / shift / mask sequence, and the
+// interval word is unpacked and the record packed on the chain.  Here a stream is coded by TWO adjacent lanes, role 0 holding
+// u = low and role 1 holding u = ~high, so that ONE instruction sequence updates both bounds:
+//     role 0   low'   = low   + floor(span * c_low / 2^16)
+//     role 1   ~high' = ~high + ceil(span * (2^16 - c_high) / 2^16)        (high - high' = span - floor(span * c_high / 2^16))
+// i.e. u' = u + role_term(range, c, round) with the role's own word c (role_word) and round = 0 / 65535.  With
+// span = range + 1 = rh * 2^16 + rl + 1 the term is rh * c + (((rl + 1) * c + round) >> 16): c <= 65535, so every product
+// fits 32 bits and the multiplies are the full-rate 24-bit ones.  The renormalisation needs nothing but the pair's u':
+//     a = u'_0 ^ u'_1 = ~(low' ^ high'),  z = u'_0 & u'_1 = low' & ~high'
+//     n + m = clz(~(a | z << 1))     (n leading agreeing bits, the differing bit, then the m bits of the underflow run)
+//     u = (u' << (n + m)) & 0x7FFFFFFF for BOTH roles,  range = ~(u_0 + u_1)
+// and the record of the symbol is the pair (low', ~high') itself: phase 2, parallel over symbols, derives n, m and the
+// emitted bits from it (record_from_pair), so nothing is unpacked or packed on the chain.  ~15 instructions per symbol.
+// Precondition as for the whole encoder: c_high > c_low (then low' < high' and n + m <= 31).
+L3C_HD uint32_t role_word(uint32_t c_lo, uint32_t c_hi, int role) { return role ? 0x10000u - c_hi : c_lo; }
+L3C_HD uint32_t role_round(int role) { return role ? 0xFFFFu : 0u; }
+
+L3C_HD uint32_t mul24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (a & 0xFFFFFFu) * (b & 0xFFFFFFu);
+#endif
+}
+
+L3C_HD uint32_t role_term(uint32_t range, uint32_t c, uint32_t round) {
+    const uint32_t rl = range & 0xFFFFu, rh = range >> 16;
+    return mul24(rh, c) + ((mul24(rl, c) + c + round) >> 16);
+}
+
+L3C_HD int role_shift(uint32_t u_self, uint32_t u_other) {
+    const uint32_t h = ~((u_self ^ u_other) | ((u_self & u_other) << 1));   // != 0 for low' < high'
+#if defined(__HIP_DEVICE_COMPILE__)
+    int t;
+    asm("v_ffbh_u32 %0, %1" : "=v"(t) : "v"(h));   // clz32 costs a v_min on top; -1 for h == 0, the shifts use 5 bits
+    return t;
+#else
+    return clz32(h) & 31;
+#endif
+}
+L3C_HD uint32_t role_renorm(uint32_t u, int t) { return (u << (t & 31)) & 0x7FFFFFFFu; }
+L3C_HD uint32_t role_range(uint32_t u_self, uint32_t u_other) { return ~(u_self + u_other); }
+
+// The packed record (pack_record) of a symbol from the pair phase 1 left in its two interval words.
+L3C_HD uint32_t record_from_pair(uint32_t low1, uint32_t not_high1) {
+    int n, m;
+    uint32_t nl, nh;
+    renorm_counts(low1, ~not_high1, n, m, nl, nh);
+    return pack_record(low1, (uint32_t)n | ((uint32_t)m << 8));
+}
 
 // Literal (serial) emission of one record -- the definition phase 2 must reproduce; also used for its rare long runs.
 template <class Sink>

@@ -1,9 +1,9 @@
 // ac_kernels.hip -- range coder on the GPU (replaces the CPU coder of torchac.cpp).
 //
-//   intervals_from_table_kernel   table + symbols -> packed (c_low, c_high) words          (fully parallel)
-//   ac_state_kernel               encoder phase 1, one stream per LANE (64 streams per wavefront): only the serial interval
-//                                 recurrence of csrc/ac_core.h, branch-free; each interval word is replaced in place by
-//                                 a record (top bits, n, m)
+//   intervals_from_table_kernel   table + symbols -> the two role words of every symbol     (fully parallel)
+//   ac_state_kernel               encoder phase 1, one stream per LANE PAIR (32 streams per wavefront): only the serial
+//                                 interval recurrence in the role-symmetric form of csrc/ac_core.h, branch-free; each
+//                                 interval word is replaced in place by its role's bound after the update (low' / ~high')
 //   ac_pack_kernel                encoder phase 2, one stream per WAVEFRONT, 64 symbols per step: pending runs by a segmented
 //                                 wave scan, bit offsets by a prefix sum, bits merged with LDS atomics, words written coalesced
 //   ac_decode_ring_kernel         one stream per WAVEFRONT: the table streams through an LDS ring by LDS-DMA, lanes hold the CDF
@@ -21,6 +21,12 @@ namespace {
 
 constexpr int kChunk = 64;  // symbols per interval block (see l3c_interval_words)
 
+// Interval words (include/l3c_hip.h): per 64-symbol block and stream TWO runs of 64 words, one per role of the lane pair
+// that codes the stream (csrc/ac_core.h: role_word).
+__device__ __forceinline__ int64_t iv_index(int64_t chunk, int64_t n_streams, int64_t s, int role, int j) {
+    return ((chunk * n_streams + s) * 2 + role) * kChunk + j;
+}
+
 __global__ __launch_bounds__(256) void intervals_from_table_kernel(const uint16_t *__restrict__ cdf, int64_t row_stride,
                                                                    int Lp, const int16_t *__restrict__ sym,
                                                                    int64_t n_streams, int64_t n_sym,
@@ -28,80 +34,118 @@ __global__ __launch_bounds__(256) void intervals_from_table_kernel(const uint16_
     const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
     const int64_t total = n_chunks * n_streams * kChunk;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = i % kChunk;
+        const int j = (int)(i % kChunk);
         const int64_t s = (i / kChunk) % n_streams;
-        const int64_t t = (i / kChunk / n_streams) * kChunk + j;
-        uint32_t w = 0;
+        const int64_t chunk = i / kChunk / n_streams;
+        const int64_t t = chunk * kChunk + j;
+        uint32_t w0 = 0, w1 = 0;
         if (t < n_sym) {
             const int x = sym[s * n_sym + t];
             const uint16_t *row = cdf + (row_stride ? (s * n_sym + t) * row_stride : 0);
             const uint32_t c_lo = row[x];
             const uint32_t c_hi = (x == Lp - 2) ? 0x10000u : (uint32_t)row[x + 1];
-            w = l3c::pack_interval(c_lo, c_hi);
+            w0 = l3c::role_word(c_lo, c_hi, 0);
+            w1 = l3c::role_word(c_lo, c_hi, 1);
         }
-        iv[i] = w;
+        iv[iv_index(chunk, n_streams, s, 0, j)] = w0;
+        iv[iv_index(chunk, n_streams, s, 1, j)] = w1;
     }
 }
 
-// ---- encoder, phase 1: interval recurrence, one stream per lane ---------------------------------------------------------
-// Reads 16 interval words at a time (4 x dwordx4, next group prefetched) and overwrites each with its record
-// (csrc/ac_core.h: pack_record) -- same address, so no extra memory and no read/write hazard (a lane only ever touches its
-// own 64-word runs, in order).
+// ---- encoder, phase 1: interval recurrence, one stream per lane PAIR ----------------------------------------------------
+// Lanes 2i / 2i+1 are the two roles of stream i (csrc/ac_core.h: role 0 holds low, role 1 ~high; the partner's value comes
+// through a DPP quad permute, which the compiler folds into the xor / and / add that consumes it).  A lane reads its role's
+// 64 words of a block as 16 x dwordx4 (the next block already in flight) and overwrites each with u' -- same address, so no
+// extra memory and no read/write hazard (a lane only ever touches its own 64-word runs, in order).
+// The grouped launches read their buffer pointers from a descriptor in memory, so the compiler cannot prove them global and
+// emits FLAT accesses -- whose completion it can only await with vmcnt(0): the block-ahead prefetch below (and phase 2's ring
+// of records) then waited for the loads it had just issued, a full HBM round trip per 64 symbols (18.5 -> 11 ms per
+// 393 216-symbol stream in phase 1).  Typed global pointers give global_load / global_store and exact vmcnt counts.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 gu32x4;
+typedef __attribute__((address_space(1))) uint32_t gu32;
+
+__device__ __forceinline__ uint32_t pair_partner(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+
+// One symbol of a lane pair (csrc/ac_core.h: role_term / role_shift / role_renorm, restated for the DEPTH of the dependent
+// chain: a lone wavefront waits ~7 cycles for the result of the previous instruction, so what counts is the longest path from
+// `range` to the next `range`, 9 instructions here):
+//     range -> rl * c -> + c + round -> u' = (u + rh * c) + (q >> 16)          [3; u + rh * c beside them]
+//     u' -> u' << 1 -> & partner's -> ~((u' ^ o) | .) -> ffbh = n + m          [4; o = partner's u' and S = u' + o beside them]
+//     n + m -> S << (n + m) -> ~ = range                                        [2: range = ((high' - low' + 1) << (n + m)) - 1
+//                                                                                   and high' - low' + 1 = -S]
+// the renormalised bound u = (u' << (n + m)) & 0x7FFFFFFF is only needed by the NEXT symbol's last addition.
+__device__ __forceinline__ uint32_t pair_step(uint32_t &u, uint32_t &range, uint32_t c, uint32_t round) {
+    const uint32_t q = l3c::mul24(range & 0xFFFFu, c) + c + round;
+    const uint32_t base = u + l3c::mul24(range >> 16, c);
+    uint32_t u1;                                          // base + (q >> 16) == u + role_term(range, c, round), the shift as an operand select
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(u1) : "v"(base), "v"(q));
+    const uint32_t o1 = pair_partner(u1);
+    const uint32_t sum = u1 + o1;                         // low' + ~high' = -(high' - low' + 1)
+    const uint32_t us = u1 << 1;
+    const uint32_t zz = us & pair_partner(us);            // (low' & ~high') << 1
+    const uint32_t h = ~((u1 ^ o1) | zz);
+    int t;
+    asm("v_ffbh_u32 %0, %1" : "=v"(t) : "v"(h));         // == role_shift(u1, o1); h != 0 for low' < high'
+    range = ~(sum << t);                                  // == role_range of the renormalised pair
+    u = (u1 << t) & 0x7FFFFFFFu;                          // == role_renorm(u1, t)
+    asm volatile("" : "+v"(range));   // keep `range` a value of its own: its two halves then feed the 24-bit multiplies as SDWA selects
+    return u1;
+}
+
 __device__ __forceinline__ void ac_state_body(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
                                               uint32_t *__restrict__ final_low, int64_t block) {
-    int64_t s = block * 64 + threadIdx.x;
+    int64_t s = block * 32 + (threadIdx.x >> 1);
+    const int role = threadIdx.x & 1;
     const bool active = s < n_streams;
     if (!active) s = n_streams - 1;   // keep the wavefront converged; duplicates rewrite identical values
-    uint32_t low = 0, high = 0xFFFFFFFFu;
+    uint32_t u = 0, range = 0xFFFFFFFFu;   // low = 0, high = 0xFFFFFFFF
+    const uint32_t round = l3c::role_round(role);
     __builtin_amdgcn_s_setprio(3);    // a few long-lived latency-bound waves next to MFMA-heavy kernels: issue first
 
-    // One 64-symbol block (16 x dwordx4 per lane) is processed while the next one is already in flight: ~8 us of serial
+    // One 64-symbol block (16 x dwordx4 per lane) is processed while the next one is already in flight: ~2 us of serial
     // work per block hides the HBM latency even when the conv kernels of the next batch saturate the memory system.
     const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
-    auto chunk_ptr = [&](int64_t c) { return reinterpret_cast<uint4 *>(iv + (c * n_streams + s) * kChunk); };
-    uint4 cur[16], nxt[16];
+    auto chunk_ptr = [&](int64_t c) { return (gu32x4 *)(iv + iv_index(c, n_streams, s, role, 0)); };
+    u32x4 cur[16], nxt[16];
     {
-        const uint4 *p = chunk_ptr(0);
+        const gu32x4 *p = chunk_ptr(0);
 #pragma unroll
         for (int k = 0; k < 16; ++k) cur[k] = p[k];
     }
     for (int64_t c = 0; c < n_chunks; ++c) {
-        if (c + 1 < n_chunks) {
-            const uint4 *p = chunk_ptr(c + 1);
+        {   // UNCONDITIONAL (the last block is fetched again and dropped): with a skipped prefetch as a second path into the
+            // code below the compiler has to await `cur` with vmcnt(0) -- i.e. the loads just issued
+            const gu32x4 *p = chunk_ptr(c + 1 < n_chunks ? c + 1 : c);
 #pragma unroll
             for (int k = 0; k < 16; ++k) nxt[k] = p[k];
         }
-        uint4 *dst = chunk_ptr(c);
+        gu32x4 *dst = chunk_ptr(c);
         const int64_t left = n_sym - c * kChunk;
         if (left >= kChunk) {
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t rl, rn;
-                    l3c::encode_state_step(low, high, w[j], rl, rn);
-                    w[j] = l3c::pack_record(rl, rn);
-                }
-                if (active) dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int j = 0; j < 4; ++j) w[j] = pair_step(u, range, w[j], round);
+                if (active) dst[k] = u32x4{w[0], w[1], w[2], w[3]};
             }
         } else {   // ragged last block
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 uint32_t w[4] = {cur[k].x, cur[k].y, cur[k].z, cur[k].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    uint32_t rl = 0, rn = 0;
-                    if (k * 4 + j < (int)left) l3c::encode_state_step(low, high, w[j], rl, rn);   // wave-uniform test
-                    w[j] = l3c::pack_record(rl, rn);
-                }
-                if (active) dst[k] = make_uint4(w[0], w[1], w[2], w[3]);
+                for (int j = 0; j < 4; ++j)
+                    if (k * 4 + j < (int)left) w[j] = pair_step(u, range, w[j], round);   // wave-uniform test
+                if (active) dst[k] = u32x4{w[0], w[1], w[2], w[3]};
             }
         }
 #pragma unroll
         for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
     }
-    if (active) final_low[s] = low;
+    if (active && role == 0) final_low[s] = u;
 }
 
 // One group of equally long streams for the grouped launches (mirrors l3c_ac_group of include/l3c_hip.h).
@@ -127,12 +171,12 @@ __global__ __launch_bounds__(64) void ac_state_kernel(uint32_t *__restrict__ iv,
     ac_state_body(iv, n_streams, n_sym, final_low, blockIdx.x);
 }
 
-// Grouped launch: block -> (group, 64-stream block inside the group) by walking the (short) descriptor array.
+// Grouped launch: block -> (group, 32-stream block inside the group) by walking the (short) descriptor array.
 __global__ __launch_bounds__(64) void ac_state_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
     int64_t blk = blockIdx.x;
     int g = 0;
     for (; g < n_groups; ++g) {
-        const int64_t nb = (groups[g].n_streams + 63) / 64;
+        const int64_t nb = (groups[g].n_streams + 31) / 32;
         if (blk < nb) break;
         blk -= nb;
     }
@@ -150,10 +194,39 @@ struct GlobalWordStore {
     }
 };
 
-__device__ __forceinline__ uint32_t wave_shfl_up(uint32_t v, int d, int lane) {
-    const uint32_t o = (uint32_t)__shfl_up((int)v, d, 64);
-    return lane >= d ? o : 0u;
+// Wave scans by DPP (round 4; before: __shfl_up = ds_bpermute, ~100 cycles of LDS-crossbar latency per level, 19 of them on
+// the serial path of every 64-symbol step).  dpp0<CTRL, ROWS>(v): the value of the lane CTRL names, 0 where there is none
+// (row_shr beyond the start of a 16-lane row) or for rows outside ROWS.  Hillis-Steele inside the rows (row_shr 1, 2, 4, 8),
+// then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2, 3 (row_bcast:31).
+template <int CTRL, int ROWS = 0xF>
+__device__ __forceinline__ uint32_t dpp0(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROWS, 0xF, false);
 }
+#define L3C_WAVE_SCAN_LEVELS(STEP) \
+    STEP(0x111, 0xF) STEP(0x112, 0xF) STEP(0x114, 0xF) STEP(0x118, 0xF) STEP(0x142, 0xA) STEP(0x143, 0xC)
+
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t v) {
+#define L3C_STEP(CTRL, ROWS) v += dpp0<CTRL, ROWS>(v);
+    L3C_WAVE_SCAN_LEVELS(L3C_STEP)
+#undef L3C_STEP
+    return v;
+}
+
+// segmented inclusive sum: S_j = flag_j ? val_j : S_{j-1} + val_j; on return `flag` says whether any lane <= j had its flag set
+__device__ __forceinline__ uint32_t wave_segmented_sum(uint32_t val, uint32_t &flag) {
+#define L3C_STEP(CTRL, ROWS)                          \
+    {                                                 \
+        const uint32_t v_up = dpp0<CTRL, ROWS>(val);  \
+        const uint32_t f_up = dpp0<CTRL, ROWS>(flag); \
+        val += flag ? 0u : v_up;                      \
+        flag |= f_up;                                 \
+    }
+    L3C_WAVE_SCAN_LEVELS(L3C_STEP)
+#undef L3C_STEP
+    return val;
+}
+
+__device__ __forceinline__ uint32_t wave_prev_lane(uint32_t v) { return dpp0<0x138>(v); }   // wave_shr:1; lane 0 reads 0
 
 __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__restrict__ rec, int64_t n_streams,
                                              int64_t n_sym, const uint32_t *__restrict__ final_low,
@@ -161,37 +234,39 @@ __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__re
                                              uint32_t *__restrict__ out_nbytes, int64_t s) {
     const int lane = threadIdx.x;
     uint32_t *words = reinterpret_cast<uint32_t *>(out + s * out_stride);
+    gu32 *gwords = (gu32 *)words;              // see the note at gu32: exact vmcnt counts for the ring of records below
+    const gu32 *grec = (const gu32 *)rec;
     uint32_t pending = 0;          // wave-uniform
     uint64_t bit_off = 0;          // bits emitted so far (wave-uniform)
     uint32_t carry_word = 0;       // the incomplete output word, MSB aligned
 
     const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
     constexpr int PF = 8;          // records in flight: 8 steps of 64 symbols
-    uint32_t ring[PF];
+    uint32_t ring[PF], ring_hi[PF];   // what phase 1 left of a symbol: low' and ~high' (csrc/ac_core.h: record_from_pair)
 #pragma unroll
-    for (int d = 0; d < PF; ++d) ring[d] = d < n_chunks ? rec[((int64_t)d * n_streams + s) * kChunk + lane] : 0u;
+    for (int d = 0; d < PF; ++d) {
+        ring[d] = d < n_chunks ? grec[iv_index(d, n_streams, s, 0, lane)] : 0u;
+        ring_hi[d] = d < n_chunks ? grec[iv_index(d, n_streams, s, 1, lane)] : 0u;
+    }
     for (int64_t c0 = 0; c0 < n_chunks; c0 += PF)
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int64_t c = c0 + d;
         if (c >= n_chunks) break;   // wave-uniform
-        const uint32_t r = (c * kChunk + lane < n_sym) ? ring[d] : 0u;   // a zero record emits nothing
-        if (c + PF < n_chunks) ring[d] = rec[((c + PF) * n_streams + s) * kChunk + lane];
+        const uint32_t r = (c * kChunk + lane < n_sym) ? l3c::record_from_pair(ring[d], ring_hi[d]) : 0u;   // a zero record emits nothing
+        {   // unconditional, clamped: see ac_state_body
+            const int64_t cn = c + PF < n_chunks ? c + PF : n_chunks - 1;
+            ring[d] = grec[iv_index(cn, n_streams, s, 0, lane)];
+            ring_hi[d] = grec[iv_index(cn, n_streams, s, 1, lane)];
+        }
         const uint32_t n = l3c::record_n(r), m = l3c::record_m(r), top = l3c::record_top(r);
         const bool emits = n != 0;
         // segmented inclusive scan: S_j = emits_j ? m_j : S_{j-1} + m_j  (a run of pending bits restarts at every emitter)
-        uint32_t val = m;
         uint32_t flag = emits ? 1u : 0u;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t v_up = wave_shfl_up(val, d, lane);
-            const uint32_t f_up = wave_shfl_up(flag, d, lane);
-            if (!flag) val += v_up;
-            flag |= f_up;
-        }
+        uint32_t val = wave_segmented_sum(m, flag);
         if (!flag) val += pending;                     // no emitter at or before this lane: the carried run continues
         // pending BEFORE symbol j = S_{j-1} (exclusive), S_{-1} = carried pending
-        uint32_t p_before = (uint32_t)__shfl_up((int)val, 1, 64);
+        uint32_t p_before = wave_prev_lane(val);
         if (lane == 0) p_before = pending;
         const uint32_t e = emits ? n + p_before : 0u;  // bits this symbol emits
         const uint32_t new_pending = (uint32_t)__builtin_amdgcn_readlane((int)val, 63);
@@ -217,9 +292,7 @@ __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__re
         }
 
         // exclusive prefix sum of e -> bit position of every symbol inside this step's window
-        uint32_t incl = e;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) incl += wave_shfl_up(incl, d, lane);
+        const uint32_t incl = wave_inclusive_sum(e);
         const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         const uint32_t base = (uint32_t)(bit_off & 31u);
         const uint32_t pos = base + incl - e;
@@ -243,8 +316,8 @@ __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__re
         const uint32_t window_bits = base + total;
         const uint32_t full = window_bits >> 5;        // complete words in the window (<= 65)
         const uint32_t first_word = (uint32_t)(bit_off >> 5);
-        if ((uint32_t)lane < full) words[first_word + lane] = l3c::bswap32(buf[lane]);
-        if ((uint32_t)lane + 64u < full) words[first_word + 64 + lane] = l3c::bswap32(buf[64 + lane]);
+        if ((uint32_t)lane < full) gwords[first_word + lane] = l3c::bswap32(buf[lane]);
+        if ((uint32_t)lane + 64u < full) gwords[first_word + 64 + lane] = l3c::bswap32(buf[64 + lane]);
         carry_word = (window_bits & 31u) ? buf[full] : 0u;
         __syncthreads();
         bit_off += total;
@@ -880,7 +953,7 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
 extern "C" {
 
 int64_t l3c_interval_words(int64_t n_streams, int64_t n_sym) {
-    return ((n_sym + kChunk - 1) / kChunk) * n_streams * kChunk;
+    return ((n_sym + kChunk - 1) / kChunk) * n_streams * kChunk * 2;
 }
 
 int64_t l3c_ac_max_bytes(int64_t n_sym) {
@@ -911,7 +984,7 @@ int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t
     L3C_REQUIRE((reinterpret_cast<uintptr_t>(out) & 3) == 0 && (reinterpret_cast<uintptr_t>(intervals) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(workspace) & 3) == 0, "misaligned buffer");
     uint32_t *final_low = static_cast<uint32_t *>(workspace);
-    const int blocks = (int)((n_streams + 63) / 64);
+    const int blocks = (int)((n_streams + 31) / 32);   // a lane pair per stream
     hipLaunchKernelGGL(ac_state_kernel, dim3(blocks), dim3(64), 0, l3c::as_stream(stream), intervals, n_streams, n_sym,
                        final_low);
     int rc = l3c::check_launch("ac_state_kernel");
@@ -940,7 +1013,7 @@ int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *wo
         L3C_REQUIRE((reinterpret_cast<uintptr_t>(in.out) & 3) == 0 && (reinterpret_cast<uintptr_t>(in.intervals) & 15) == 0,
                     "misaligned buffer in group");
         host[g] = AcGroup{in.intervals, in.out, in.out_nbytes, final_low + streams, in.n_streams, in.n_sym, in.out_stride_bytes};
-        state_blocks += (in.n_streams + 63) / 64;
+        state_blocks += (in.n_streams + 31) / 32;
         pack_blocks += in.n_streams;
         streams += in.n_streams;
     }

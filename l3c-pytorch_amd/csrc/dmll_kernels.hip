@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__re
     const int64_t n_streams = (int64_t)gridDim.y * C;
     for (int w = tid; w < kHeadPix * C; w += 256) {
         const int p = w % kHeadPix, c = w / kHeadPix;
-        uint32_t word = 0;
+        uint32_t word0 = 0, word1 = 0;   // the stream's lane pair reads one word per role (csrc/ac_core.h: role_word)
         if (p < npix) {
             const float *px = tile + p * ld;
             auto get = [&](int ch) { return px[ch]; };
@@ -307,9 +307,12 @@ __global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__re
             }
             const uint32_t c_lo = cdf_quantise(acc_lo, scale, x);
             const uint32_t c_hi = (x == Lp - 2) ? 0x10000u : cdf_quantise(acc_hi, scale, x + 1);
-            word = l3c::pack_interval(c_lo, c_hi);
+            word0 = l3c::role_word(c_lo, c_hi, 0);
+            word1 = l3c::role_word(c_lo, c_hi, 1);
         }
-        iv[(chunk * n_streams + b * C + c) * kHeadPix + p] = word;
+        uint32_t *dst = iv + (chunk * n_streams + b * C + c) * (2 * kHeadPix) + p;
+        dst[0] = word0;
+        dst[kHeadPix] = word1;
     }
 }
 

@@ -35,13 +35,26 @@ long long hostsim_encode(const uint16_t *cdf, long long row_stride, int Lp, cons
     std::vector<uint32_t> words((size_t)(N / 2 + 16));
     l3c::WordSink<VecStore> sink(VecStore{words.data()});
     uint32_t low = 0, high = 0xFFFFFFFFu, pending = 0;
+    uint32_t u[2] = {0u, 0u}, range = 0xFFFFFFFFu;   // fast == 2: the lane pair of ac_state_kernel (role 0: low, role 1: ~high)
     for (long long i = 0; i < N; ++i) {
         const uint16_t *row = cdf + i * row_stride;
         const int x = sym[i];
         const uint32_t c_lo = row[x];
         const uint32_t c_hi = x == Lp - 2 ? 0x10000u : row[x + 1];
         const uint32_t w = l3c::pack_interval(c_lo, c_hi);
-        if (fast) {   // the two-phase encoder's record path (what ac_state_kernel + ac_pack_kernel implement)
+        if (fast == 2) {   // phase 1 as the two roles of a lane pair run it, phase 2's record from the pair of words it leaves
+            uint32_t u1[2];
+            for (int role = 0; role < 2; ++role)
+                u1[role] = u[role] + l3c::role_term(range, l3c::role_word(c_lo, c_hi, role), l3c::role_round(role));
+            const int t0 = l3c::role_shift(u1[0], u1[1]), t1 = l3c::role_shift(u1[1], u1[0]);
+            u[0] = l3c::role_renorm(u1[0], t0);
+            u[1] = l3c::role_renorm(u1[1], t1);
+            range = l3c::role_range(u[0], u[1]);
+            low = u[0];
+            const uint32_t r = l3c::record_from_pair(u1[0], u1[1]);
+            const uint32_t n = l3c::record_n(r);
+            l3c::emit_record(n ? l3c::record_top(r) << ((32u - n) & 31u) : 0u, n | (l3c::record_m(r) << 8), pending, sink);
+        } else if (fast) {   // the two-phase encoder's record path (what ac_state_kernel + ac_pack_kernel implement)
             uint32_t rl, rn;
             l3c::encode_state_step(low, high, w, rl, rn);
             const uint32_t r = l3c::pack_record(rl, rn);

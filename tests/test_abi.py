@@ -39,8 +39,8 @@ def test_library_is_built_and_exports_every_declared_symbol():
 
 def test_pure_host_entry_points():
     lib = _lib.load()
-    assert lib.l3c_interval_words(3, 100) == 2 * 3 * 64
-    assert lib.l3c_interval_words(48, 393216) == 393216 * 48
+    assert lib.l3c_interval_words(3, 100) == 2 * 3 * 64 * 2      # two role words per symbol
+    assert lib.l3c_interval_words(48, 393216) == 393216 * 48 * 2
     assert lib.l3c_ac_max_bytes(393216) >= 2 * 393216 + 8 and lib.l3c_ac_max_bytes(393216) % 4 == 0
     assert lib.l3c_conv_packed_words(64, 64, 3) == 64 * 64 * 9
     assert lib.l3c_conv_packed_words(120, 192, 1) == 128 * 192

@@ -15,6 +15,7 @@ def test_hostsim_kats(golden):
     for n in _names(g):
         tab, sym, ref = g[n + '/cdf'], g[n + '/sym'], g[n + '/bytes'].tobytes()
         assert hs.encode(tab, sym, fast=True) == ref, n
+        assert hs.encode(tab, sym, fast=2) == ref, n
         assert hs.encode(tab, sym, fast=False) == ref, n
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), n
         assert (hs.decode(tab, ref, len(sym), 2) == sym).all(), n
@@ -58,6 +59,7 @@ def test_hostsim_random_vs_oracle():
         tab, sym = _random_case(rng, it)
         ref = ac.encode(tab, sym)
         assert hs.encode(tab, sym, fast=True) == ref, it
+        assert hs.encode(tab, sym, fast=2) == ref, (it, 'lane pair')
         assert hs.encode(tab, sym, fast=False) == ref, it
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), it
         assert (hs.decode(tab, ref, len(sym), 2) == sym).all(), it
@@ -77,11 +79,11 @@ def test_hostsim_degenerate_intervals():
     for s in (0, 1, 2):
         sym = np.full(N, s, dtype=np.int16)
         ref = ac.encode(tab, sym)
-        assert hs.encode(tab, sym) == ref
+        assert hs.encode(tab, sym) == ref and hs.encode(tab, sym, fast=2) == ref
         assert (hs.decode(tab, ref, N, True) == sym).all()
     tab[:, 1] = 32768
     tab[:, 2] = 32769
     sym = np.tile(np.array([0, 2, 1, 1, 2, 0], dtype=np.int16), N // 6)
     ref = ac.encode(tab, sym)
-    assert hs.encode(tab, sym) == ref and hs.encode(tab, sym, fast=False) == ref
+    assert hs.encode(tab, sym) == ref and hs.encode(tab, sym, fast=False) == ref and hs.encode(tab, sym, fast=2) == ref
     assert (hs.decode(tab, ref, N, False) == sym).all()
