@@ -905,6 +905,409 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
     if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.pos, {0u, 0u, 0u, 0u}};
 }
 
+// ---- the lean fast decoder (round 4) --------------------------------------------------------------------------------------
+// What the FAST ring decoder above spends on a symbol is ~130 instructions, and a lone wavefront issues one every ~5 cycles
+// whatever they are: the chain costs its instruction COUNT.  Same ring, same arithmetic, same DecodeState between chunks,
+// ~40 % fewer instructions per symbol:
+//   * rows land in the HIGH half-words of two alternating register sets (ds_read_u16_d16_hi; the low halves are zero and
+//     stay zero): no shift, no copy out of a staging set; the loop is unrolled by two rows
+//   * the state is (low, ~high, range) as in the encoder's lane pairs (csrc/ac_core.h): ONE count n + m renormalises both
+//     bounds, range = ~(low + ~high), the underflow flip of `value` is the bit the shift pushes out of low
+//   * the bit reader is a 64-bit buffer of upcoming bits: consuming n + m <= 31 bits is one 64-bit shift of value:buffer,
+//     a word is pulled out of the window register only when fewer than 32 bits are left (every ~5 symbols)
+//   * full ring blocks hold neither the stream's last symbol nor a ragged end: no per-symbol tests for either; decoded
+//     symbols are kept in lane (row within the block) and stored once per block
+//   * Lp == 257 (the RGB alphabet): all 256 entries of the four registers are table entries, no validity masks
+// A stream whose value leaves [low, high] (never for a stream of this coder or the reference) marks itself and is redone by
+// the generic instantiation, exactly as before.
+template <int NJ>
+struct RowHi;
+template <>
+struct RowHi<1> {
+    uint32_t a;
+};
+template <>
+struct RowHi<4> {
+    uint32_t a, b, c, d;
+};
+__device__ __forceinline__ void row_hi_issue(uint32_t addr, RowHi<1> &r) {
+    asm volatile("ds_read_u16_d16_hi %0, %1" : "+v"(r.a) : "v"(addr));
+}
+__device__ __forceinline__ void row_hi_issue(uint32_t addr, RowHi<4> &r) {
+    asm volatile(
+        "ds_read_u16_d16_hi %0, %4\n\tds_read_u16_d16_hi %1, %4 offset:128\n\tds_read_u16_d16_hi %2, %4 offset:256\n\t"
+        "ds_read_u16_d16_hi %3, %4 offset:384"
+        : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d)
+        : "v"(addr));
+}
+// the reads of row_hi_issue have landed; ties the registers to the wait so that no use moves above it
+__device__ __forceinline__ void row_hi_wait(RowHi<1> &r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a)); }
+__device__ __forceinline__ void row_hi_wait(RowHi<4> &r) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r.a), "+v"(r.b), "+v"(r.c), "+v"(r.d));
+}
+__device__ __forceinline__ RowHi<1> row_mul_hi(const RowHi<1> &r, uint32_t s) { return RowHi<1>{mul_hi(r.a, s)}; }
+__device__ __forceinline__ RowHi<4> row_mul_hi(const RowHi<4> &r, uint32_t s) {
+    return RowHi<4>{mul_hi(r.a, s), mul_hi(r.b, s), mul_hi(r.c, s), mul_hi(r.d, s)};
+}
+template <bool ALLVALID>
+__device__ __forceinline__ uint32_t row_rank(const RowHi<1> &t, uint32_t d, const ValidLanes<1> &v) {
+    return ALLVALID ? count_le(t.a, d) : count_le_valid(t.a, d, v.a);
+}
+template <bool ALLVALID>
+__device__ __forceinline__ uint32_t row_rank(const RowHi<4> &t, uint32_t d, const ValidLanes<4> &v) {
+    if (ALLVALID) return (count_le(t.a, d) + count_le(t.b, d)) + (count_le(t.c, d) + count_le(t.d, d));
+    return (count_le_valid(t.a, d, v.a) + count_le_valid(t.b, d, v.b)) + (count_le_valid(t.c, d, v.c) + count_le_valid(t.d, d, v.d));
+}
+__device__ __forceinline__ void row_fetch2(const RowHi<1> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
+    lo = lane_read(r.a, x & 63u);
+    hi = lane_read(r.a, x1 & 63u);
+}
+__device__ __forceinline__ void row_fetch2(const RowHi<4> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
+    const uint32_t j = x >> 6;
+    const uint32_t ab = j & 1u ? r.b : r.a, cd = j & 1u ? r.d : r.c;
+    const uint32_t sel = j & 2u ? cd : ab;
+    lo = lane_read(sel, x & 63u);
+    if (__builtin_expect((x1 & 63u) != 0u, 1)) {
+        hi = lane_read(sel, x1 & 63u);
+    } else {
+        const uint32_t j1 = x1 >> 6;   // 1..4; 4 (x == top == 255) is replaced by the caller
+        const uint32_t bc = j1 & 1u ? r.b : r.c;
+        hi = lane_read(j1 == 3u ? r.d : bc, 0u);
+    }
+}
+
+struct LeanState {
+    uint32_t low, nh, range;          // nh = ~high, range = high - low
+    uint64_t vb;                      // high word: value; low word: scratch (the next 32 bits are copied in before a shift)
+    uint64_t buf;                     // upcoming bits of the stream, MSB first
+    uint32_t nbits;                   // valid bits in buf: >= 32 before every symbol
+    uint32_t widx;                    // next stream word to enter buf
+    uint32_t bad;                     // != 0: value left [low, high] at some symbol (checked once per ring block)
+};
+
+// One symbol on a validated table.  A value outside [low, high] only raises st.bad (the state then runs on garbage until the
+// block ends: every index it forms is masked by the hardware, stream words past the end read as zero).
+template <int NJ, bool ALLVALID, bool FULL>
+__device__ __forceinline__ void lean_symbol_body(const RowHi<NJ> &row, const ValidLanes<NJ> &valid, uint32_t top, bool advance,
+                                                 LeanState &st, WaveBits &src, uint32_t &x) {
+    const uint32_t d = (uint32_t)(st.vb >> 32) - st.low;
+    st.bad |= d > st.range ? 1u : 0u;
+    uint32_t x1, t_lo, t_hi;
+    RowHi<NJ> t;
+    if (FULL) t = row;
+    else t = row_mul_hi(row, st.range + 1u);
+    const uint32_t rank = row_rank<ALLVALID>(t, d, valid);
+    x1 = rank > 1u ? rank : 1u;            // x + 1
+    asm("" : "+s"(x1));                    // keep it scalar: max - 1 would be canonicalised to a VALU-only saturating subtract
+    x = x1 - 1u;
+    row_fetch2(t, x, x1, t_lo, t_hi);
+    if (advance) {   // x == top: t_hi is not a table entry, replaced
+        const uint32_t lo = st.low + t_lo;
+        const uint32_t nh1 = x == top ? st.nh : 0u - (st.low + t_hi);   // ~(low - 1 + t_hi); the top symbol keeps high
+        // csrc/ac_core.h, role_shift: n + m = clz of (lo ^ hi) & ~((lo & ~hi) << 1); <= 31, and != 0 as lo < hi
+        const uint32_t h = ~((lo ^ nh1) | ((lo & nh1) << 1));
+        const int c = __builtin_clz(h);
+        const uint32_t lo_s = lo << c;
+        const uint32_t msb = lo_s & 0x80000000u;   // set iff m > 0: the bit the underflow steps take out of low and value
+        st.low = lo_s ^ msb;
+        st.nh = (nh1 << c) & 0x7FFFFFFFu;
+        st.range = ~(st.low + st.nh);
+        // ((value << n | bits_n) << m ^ msb) | bits_m  ==  (value << c | bits_c) ^ msb
+        st.vb = (((st.vb & 0xFFFFFFFF00000000ull) | (st.buf >> 32)) << c) ^ ((uint64_t)msb << 32);
+        st.buf <<= c;
+        st.nbits -= (uint32_t)c;
+        if (__builtin_expect(st.nbits < 32u, 0)) {
+            st.buf |= (uint64_t)src.word(st.widx) << (32u - st.nbits);
+            st.widx += 1u;
+            st.nbits += 32u;
+        }
+    }
+}
+template <int NJ, bool ALLVALID>
+__device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLanes<NJ> &valid, uint32_t top, bool advance,
+                                            LeanState &st, WaveBits &src, uint32_t &x) {
+    // the interval is the whole 32-bit range (span = 2^32: the first symbol, and again whenever a symbol's interval is an aligned
+    // power of two): (span * cdf) >> 16 is cdf << 16 itself -- a separate instantiation of the whole symbol
+    if (__builtin_expect(st.range == 0xFFFFFFFFu, 0)) lean_symbol_body<NJ, ALLVALID, true>(row, valid, top, advance, st, src, x);
+    else lean_symbol_body<NJ, ALLVALID, false>(row, valid, top, advance, st, src, x);
+}
+
+// ---- a FULL ring block of the 256-symbol alphabet as one hand-written loop ---------------------------------------------------
+// What a lone wavefront pays for (tools/issue_microbench.hip, ns per instruction at ~2.4 GHz): 1.75 for almost anything, vector
+// or scalar, dependent or not -- but 10 for a v_cmp -> s_bcnt1 pair on the same vcc (four pairs back to back, as the compiler
+// emits them: 40; four v_cmp into four SGPR pairs and then four s_bcnt1: 20), +8 when a v_readlane result is needed by the
+// scalar unit at once, 8.4 for a taken branch, 4.2 for a conditional branch that is not taken, 1.75 for every s_nop.  The
+// compiler's symbol (lean_symbol above) has ~85 instructions with six conditional branches, two or three of them taken, and
+// the compares on one vcc: 290 ns.  Here a symbol is 66 instructions WITHOUT A BRANCH:
+//   * the conditions that need other code are only RECORDED -- value outside [low, high] (bad), the interval being the whole
+//     32-bit range at a symbol (minspan == 0: span = range + 1 wraps) -- and the caller decodes the block again from the saved
+//     state with lean_symbol if one was; the bit window cannot run out inside a block (the caller checks: <= 1 word a symbol)
+//   * the register holding entry x (and the one holding x + 1) is picked by VGPR indexing (s_set_gpr_idx_on over v96..v100,
+//     fixed registers so that they are consecutive) instead of scalar tests, v_cndmask and the hand-over back
+//   * the refill of the bit buffer is arithmetic: the word is read every symbol (v_readlane, off the chain) and or-ed in as
+//     zero when it is not needed
+//   * value : next 32 bits, the bit buffer and the refill word live in fixed SGPR pairs (s[94:101]), whose halves the 32-bit
+//     instructions can name; the decoded symbol goes to lane (row in the block) of `kept` by v_writelane with M0 as the lane
+//     select (gfx9's constant bus takes one SGPR)
+// Rows: set A holds the current row on entry and the first row of the next block on exit; the loop takes two rows a turn.
+#define L3C_ROW_READS(R0, R1, R2, R3, ADDR)                                                                        \
+    "ds_read_u16_d16_hi " R0 ", " ADDR "\n\tds_read_u16_d16_hi " R1 ", " ADDR " offset:128\n\t"                     \
+    "ds_read_u16_d16_hi " R2 ", " ADDR " offset:256\n\tds_read_u16_d16_hi " R3 ", " ADDR " offset:384\n\t"
+#define L3C_SYMBOL(R0, R1, R2, R3, SET_M0_TO_ROW)                                                                   \
+    "s_add_u32 %[span], %[range], 1\n\t"                                                                            \
+    "s_min_u32 %[minspan], %[minspan], %[span]\n\t"                                                                 \
+    "s_sub_u32 %[d], s97, %[low]\n\t"                      /* d = value - low */                                    \
+    "s_sub_u32 %[t0], %[range], %[d]\n\t"                  /* SCC = d > range */                                    \
+    "s_addc_u32 %[bad], %[bad], 0\n\t"                                                                              \
+    "v_mul_hi_u32 v96, " R0 ", %[span]\n\tv_mul_hi_u32 v97, " R1 ", %[span]\n\t"                                    \
+    "v_mul_hi_u32 v98, " R2 ", %[span]\n\tv_mul_hi_u32 v99, " R3 ", %[span]\n\t"                                    \
+    "v_cmp_ge_u32_e64 %[m0], %[d], v96\n\tv_cmp_ge_u32_e64 %[m1], %[d], v97\n\t"                                    \
+    "v_cmp_ge_u32_e64 %[m2], %[d], v98\n\tv_cmp_ge_u32_e64 %[m3], %[d], v99\n\t"                                    \
+    "s_bcnt1_i32_b64 %[r0], %[m0]\n\ts_bcnt1_i32_b64 %[r1], %[m1]\n\t"                                              \
+    "s_bcnt1_i32_b64 %[r2], %[m2]\n\ts_bcnt1_i32_b64 %[r3], %[m3]\n\t"                                              \
+    "s_add_i32 %[r0], %[r0], %[r1]\n\ts_add_i32 %[r2], %[r2], %[r3]\n\ts_add_i32 %[r0], %[r0], %[r2]\n\t"           \
+    "s_max_u32 %[x1], %[r0], 1\n\ts_add_i32 %[x], %[x1], -1\n\t"                                                    \
+    "s_lshr_b32 %[r1], %[x], 6\n\ts_lshr_b32 %[r2], %[x1], 6\n\t"                                                   \
+    "s_set_gpr_idx_on %[r1], 1\n\tv_mov_b32 %[sel], v96\n\t"      /* the register of entry x ...      */            \
+    "s_set_gpr_idx_idx %[r2]\n\tv_mov_b32 %[sel1], v96\n\t"       /* ... and of entry x + 1 (v100: x == top, replaced) */ \
+    "s_set_gpr_idx_off\n\t"                                                                                         \
+    "v_readlane_b32 %[lo], %[sel], %[x]\n\tv_readlane_b32 %[hi], %[sel1], %[x1]\n\t"                                \
+    SET_M0_TO_ROW "\n\t"                                                                                            \
+    "v_readlane_b32 %[w], %[cur], %[wrel]\n\t"             /* the next stream word, whether needed or not */         \
+    "v_writelane_b32 %[kept], %[x], m0\n\t"                                                                         \
+    "s_add_u32 %[lo], %[lo], %[low]\n\t"                   /* low' */                                               \
+    "s_add_u32 %[hi], %[hi], %[low]\n\ts_sub_u32 %[hi], 0, %[hi]\n\t"      /* ~high' = -(low + t_hi) */             \
+    "s_cmp_eq_u32 %[x], %[top]\n\ts_cselect_b32 %[hi], %[nh], %[hi]\n\t"   /* the top symbol keeps high */           \
+    "s_and_b32 %[r0], %[lo], %[hi]\n\ts_xor_b32 %[r1], %[lo], %[hi]\n\ts_lshl_b32 %[r0], %[r0], 1\n\t"              \
+    "s_nor_b32 %[r0], %[r0], %[r1]\n\ts_flbit_i32_b32 %[c], %[r0]\n\t"     /* c = n + m */                          \
+    "s_lshl_b32 %[lo], %[lo], %[c]\n\ts_and_b32 %[r1], %[lo], 0x80000000\n\ts_xor_b32 %[low], %[lo], %[r1]\n\t"     \
+    "s_lshl_b32 %[hi], %[hi], %[c]\n\ts_and_b32 %[nh], %[hi], 0x7fffffff\n\t"                                       \
+    "s_add_u32 %[r2], %[low], %[nh]\n\ts_not_b32 %[range], %[r2]\n\t"                                               \
+    "s_mov_b32 s96, s99\n\ts_lshl_b64 s[96:97], s[96:97], %[c]\n\ts_xor_b32 s97, s97, %[r1]\n\t"  /* value */        \
+    "s_lshl_b64 s[98:99], s[98:99], %[c]\n\ts_sub_u32 %[nbits], %[nbits], %[c]\n\t"                                 \
+    "s_cmp_lt_u32 %[nbits], 32\n\ts_cselect_b32 s100, %[w], 0\n\ts_cselect_b32 %[r3], 1, 0\n\t"                     \
+    "s_sub_u32 %[r2], 32, %[nbits]\n\ts_lshl_b64 s[94:95], s[100:101], %[r2]\n\ts_or_b64 s[98:99], s[98:99], s[94:95]\n\t" \
+    "s_lshl_b32 %[r2], %[r3], 5\n\ts_add_u32 %[nbits], %[nbits], %[r2]\n\ts_add_u32 %[wrel], %[wrel], %[r3]\n\t"
+
+__device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, LeanState &st, uint32_t &wrel, uint32_t &minspan,
+                                               uint32_t window, int &kept, uint32_t addr_next, uint32_t addr_cross,
+                                               uint32_t row_bytes, uint32_t R, uint32_t top) {
+    uint64_t m0, m1, m2, m3;
+    uint32_t span, d, t0, r0, r1, r2, r3, x, x1, lo, hi, w, c, sel, sel1, a2;
+    uint32_t value = (uint32_t)(st.vb >> 32), j = 0;
+    asm volatile(
+        "s_mov_b32 s97, %[value]\n\ts_mov_b64 s[98:99], %[buf]\n\ts_mov_b32 s101, 0\n"
+        "1:\n\t"
+        L3C_ROW_READS("%[b0]", "%[b1]", "%[b2]", "%[b3]", "%[addr]")
+        "v_add_u32 %[addr], %[rowb], %[addr]\n\t"
+        L3C_SYMBOL("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "s_mov_b32 m0, %[j]")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_add_u32 %[t0], %[j], 2\n\ts_cmp_eq_u32 %[t0], %[R]\n\ts_cselect_b64 vcc, -1, 0\n\t"
+        "v_cndmask_b32 %[a2], %[addr], %[across], vcc\n\t"      // the row after the block's last lives in the next block
+        L3C_ROW_READS("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "%[a2]")
+        "v_add_u32 %[addr], %[rowb], %[addr]\n\t"
+        L3C_SYMBOL("%[b0]", "%[b1]", "%[b2]", "%[b3]", "s_add_u32 m0, %[j], 1")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_add_u32 %[j], %[j], 2\n\ts_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[value], s97\n\ts_mov_b64 %[buf], s[98:99]"
+        : [a0] "+v"(A.a), [a1] "+v"(A.b), [a2_] "+v"(A.c), [a3] "+v"(A.d), [b0] "+v"(B.a), [b1] "+v"(B.b), [b2] "+v"(B.c),
+          [b3] "+v"(B.d), [kept] "+v"(kept), [addr] "+v"(addr_next), [low] "+s"(st.low), [nh] "+s"(st.nh), [range] "+s"(st.range),
+          [nbits] "+s"(st.nbits), [wrel] "+s"(wrel), [bad] "+s"(st.bad), [minspan] "+s"(minspan), [j] "+s"(j), [value] "+s"(value),
+          [buf] "+s"(st.buf), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [span] "=&s"(span), [d] "=&s"(d),
+          [t0] "=&s"(t0), [r0] "=&s"(r0), [r1] "=&s"(r1), [r2] "=&s"(r2), [r3] "=&s"(r3), [x] "=&s"(x), [x1] "=&s"(x1),
+          [lo] "=&s"(lo), [hi] "=&s"(hi), [w] "=&s"(w), [c] "=&s"(c), [sel] "=&v"(sel), [sel1] "=&v"(sel1), [a2] "=&v"(a2)
+        : [cur] "v"(window), [across] "v"(addr_cross), [rowb] "s"(row_bytes), [R] "s"(R), [top] "s"(top)
+        : "v96", "v97", "v98", "v99", "v100", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "m0", "scc", "vcc", "memory");
+    // what an asm statement returns counts as divergent: say that the state is wave-uniform (it already sits in SGPRs)
+    st.low = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.low);
+    st.nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.nh);
+    st.range = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.range);
+    st.nbits = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.nbits);
+    st.bad = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.bad);
+    wrel = (uint32_t)__builtin_amdgcn_readfirstlane((int)wrel);
+    minspan = (uint32_t)__builtin_amdgcn_readfirstlane((int)minspan);
+    value = (uint32_t)__builtin_amdgcn_readfirstlane((int)value);
+    const uint32_t bl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)st.buf);
+    const uint32_t bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(st.buf >> 32));
+    st.buf = ((uint64_t)bh << 32) | bl;
+    st.vb = (uint64_t)value << 32;
+}
+
+template <int NJ, bool ALLVALID, int IPB_ = (NJ == 1 ? 3 : 9)>
+__global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack pack) {
+    using C = RingCfg<NJ, IPB_>;
+    const DecodeArgs &a = pack.part[blockIdx.y];
+    if ((int64_t)blockIdx.x >= a.n_streams) return;
+    const uint16_t *cdf = a.cdf;
+    const int Lp = a.Lp;
+    const int64_t table_bytes = a.table_bytes;
+    const uint32_t n_sym = a.n_sym;
+    const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
+    __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
+    const int64_t s = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t top = (uint32_t)(Lp - 2);
+    const uint32_t row_bytes = (uint32_t)Lp * 2u;
+    const uint32_t R = (uint32_t)ring_rows_per_block(Lp, C::BLOCK_BYTES) & ~1u;   // even: the loop below takes rows in pairs
+    const uint32_t n_blocks = (n_sym + R - 1u) / R;
+    const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
+    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
+    const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
+    int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
+    if (!validated) {   // not a table for the fast path: leave the whole chunk to the generic pass
+        if (lane == 0) dst[0] = (int16_t)-1;
+        return;
+    }
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
+
+    auto request_block = [&](uint32_t k) {   // DMA the 16-byte granules holding rows [kR, (k+1)R) into slot k % NB
+        const uint64_t a = (stream0 + (uint64_t)k * R * row_bytes) & ~(uint64_t)15;
+        uint8_t *slot = ring + (k % C::NB) * C::BLOCK_BYTES;
+#pragma unroll
+        for (int q = 0; q < C::IPB; ++q) {
+            uint64_t g = a + (uint64_t)(q * 1024 + lane * 16);
+            g = g <= last_granule ? g : last_granule;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                             (__attribute__((address_space(3))) void *)(slot + q * 1024), 16, 0, 0);
+        }
+    };
+    auto block_addr = [&](uint32_t k) -> uint32_t {   // LDS byte address of this lane's first entry of row k * R
+        const uint64_t b = stream0 + (uint64_t)k * R * row_bytes;
+        return ring_base + (k % C::NB) * C::BLOCK_BYTES + (uint32_t)(b & 15u) + (uint32_t)lane * 2u;
+    };
+
+    WaveBits src;
+    const uint32_t *words = reinterpret_cast<const uint32_t *>(a.in + a.in_offsets[s]);
+    LeanState st;
+    {
+        uint32_t pos0 = 0;
+        uint32_t value = 0;
+        st.low = 0;
+        st.nh = 0;
+        st.bad = 0;
+        if (a.state_in) {
+            const DecodeState in = a.state_in[s];
+            pos0 = in.pos;
+            st.low = in.low;
+            st.nh = ~in.high;
+            value = in.value;
+        }
+        src.init(words, a.in_nbytes[s], lane, ring_base + C::NB * C::BLOCK_BYTES, pos0);   // w01 = words (pos0 >> 5), + 1
+        st.buf = src.w01 << (pos0 & 31u);
+        st.nbits = 64u - (pos0 & 31u);
+        st.widx = (pos0 >> 5) + 2u;
+        if (!a.state_in) {   // value = the first 32 bits
+            value = (uint32_t)(st.buf >> 32);
+            st.buf <<= 32;
+            st.nbits -= 32u;
+        }
+        st.vb = (uint64_t)value << 32;
+        if (st.nbits < 32u) {
+            st.buf |= (uint64_t)src.word(st.widx) << (32u - st.nbits);
+            st.widx += 1u;
+            st.nbits += 32u;
+        }
+        st.range = ~(st.low + st.nh);
+    }
+    const uint32_t no_advance = a.final_chunk ? n_sym - 1u : 0xFFFFFFFFu;   // torchac.cpp:335-337
+
+#pragma unroll
+    for (uint32_t k = 0; k < (uint32_t)C::NB - 1u; ++k)
+        if (k < n_blocks) request_block(k);
+    vm_wait<0>();
+
+    RowHi<NJ> rowA, rowB;
+    if constexpr (NJ == 1) {
+        rowA = RowHi<1>{0u};
+        rowB = RowHi<1>{0u};
+    } else {
+        rowA = RowHi<4>{0u, 0u, 0u, 0u};
+        rowB = RowHi<4>{0u, 0u, 0u, 0u};
+    }
+    row_hi_issue(block_addr(0), rowA);
+    row_hi_wait(rowA);
+
+    ValidLanes<NJ> valid;
+    if constexpr (NJ == 1) valid = valid_lanes1(lane, (int)top);
+    else valid = valid_lanes4(lane, (int)top);
+    int kept = 0;
+#define L3C_LEAN_SYMBOL(ROW, ADVANCE) lean_symbol<NJ, ALLVALID>(ROW, valid, top, ADVANCE, st, src, x);
+    for (uint32_t k = 0; k < n_blocks; ++k) {
+        // Request block k + NB - 1 (its slot held block k - 1, fully consumed), then make sure block k + 1 -- whose first row
+        // is prefetched at the end of this block -- has landed: only the two newest requests may stay in flight.
+        if (k + C::NB - 1u < n_blocks) {
+            request_block(k + C::NB - 1u);
+            if (k > 0) vm_wait<2 * C::IPB>();   // k == 0: blocks 0 .. NB-2 were waited for above
+        } else {
+            vm_wait<0>();
+        }
+        src.age += 1u;
+        const uint32_t i0 = k * R;
+        const uint32_t rows = n_sym - i0 < R ? n_sym - i0 : R;
+        const uint32_t addr_cross = block_addr(k + 1u);
+        uint32_t addr_next = block_addr(k) + row_bytes;
+        uint32_t x = 0;
+        const bool full_block = k + 1u < n_blocks;   // a full block that does not hold the stream's last symbol
+        bool done = false;
+        if constexpr (NJ == 4 && ALLVALID) {
+            // the hand-written loop, unless the bit window could run out inside the block (a symbol takes at most one word)
+            if (full_block && st.widx - src.base + R < 64u) {
+                const LeanState saved = st;
+                uint32_t wrel = st.widx - src.base, minspan = 0xFFFFFFFFu;
+                lean_block_asm(rowA, rowB, st, wrel, minspan, src.cur, kept, addr_next, addr_cross, row_bytes, R, top);
+                st.widx = src.base + wrel;
+                done = minspan != 0u && st.bad == 0u;
+                if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range or a bad value: again, the careful way
+                    st = saved;
+                    row_hi_issue(block_addr(k), rowA);
+                    row_hi_wait(rowA);
+                }
+            }
+        }
+        if (done) {
+        } else if (full_block) {   // rows in pairs, A then B
+            for (uint32_t j = 0; j < R; j += 2u) {
+                row_hi_issue(addr_next, rowB);
+                addr_next += row_bytes;
+                L3C_LEAN_SYMBOL(rowA, true)
+                kept = lane == (int)j ? (int)x : kept;
+                row_hi_wait(rowB);
+                row_hi_issue(j + 2u == R ? addr_cross : addr_next, rowA);   // the row after the block's last lives in block k + 1
+                addr_next += row_bytes;
+                L3C_LEAN_SYMBOL(rowB, true)
+                kept = lane == (int)(j + 1u) ? (int)x : kept;
+                row_hi_wait(rowA);
+            }
+        } else {                   // the last block: ragged, and its last symbol may not advance the state
+            for (uint32_t j = 0; j < rows; ++j) {
+                const bool advance = i0 + j != no_advance;
+                if (j & 1u) {
+                    row_hi_issue(addr_next, rowA);   // past the stream's last row: never used
+                    L3C_LEAN_SYMBOL(rowB, advance)
+                    row_hi_wait(rowA);
+                } else {
+                    row_hi_issue(addr_next, rowB);
+                    L3C_LEAN_SYMBOL(rowA, advance)
+                    row_hi_wait(rowB);
+                }
+                addr_next += row_bytes;
+                kept = lane == (int)j ? (int)x : kept;
+            }
+        }
+        if (__builtin_expect(st.bad != 0u, 0)) {
+            // a stream that leaves the fast path: mark it for the generic pass and stop (same lane, after any block store: the
+            // last write to dst[0])
+            vm_wait<0>();
+            if (lane == 0) dst[0] = (int16_t)-1;
+            return;
+        }
+        if ((uint32_t)lane < rows) dst[i0 + (uint32_t)lane] = (int16_t)kept;
+    }
+#undef L3C_LEAN_SYMBOL
+    if (a.state_out && lane == 0)
+        a.state_out[s] = DecodeState{st.low, ~st.nh, (uint32_t)(st.vb >> 32), st.widx * 32u - st.nbits, {0u, 0u, 0u, 0u}};
+}
+
 __global__ __launch_bounds__(256) void check_monotone_kernel(const uint16_t *__restrict__ cdf, int64_t n_rows, int Lp,
                                                              int32_t *__restrict__ flag) {
     // one thread per (row, entry m in [0, Lp-3]): requires cdf[m] < cdf[m+1]
@@ -935,10 +1338,14 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
     // table kernel of the next chunk step); the result does not depend on the ring size
     const bool crowd = max_streams * n_parts >= 48;
     if (fast_pass) {   // streams that leave the fast path (or all, if the table is not validated) mark themselves
-        if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1, true>), grid, block, 0, st, pack);
-        else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, true, 3>), grid, block, 0, st, pack);
-        else hipLaunchKernelGGL((ac_decode_ring_kernel<4, true>), grid, block, 0, st, pack);
-        const int rc = l3c::check_launch("ac_decode_ring_kernel<fast>");
+        bool full = true;   // every part codes the 256-symbol alphabet: all entries of the four row registers are table entries
+        for (int i = 0; i < n_parts; ++i) full = full && pack.part[i].Lp == 257;
+        if (small) hipLaunchKernelGGL((ac_decode_lean_kernel<1, false>), grid, block, 0, st, pack);
+        else if (crowd && full) hipLaunchKernelGGL((ac_decode_lean_kernel<4, true, 3>), grid, block, 0, st, pack);
+        else if (crowd) hipLaunchKernelGGL((ac_decode_lean_kernel<4, false, 3>), grid, block, 0, st, pack);
+        else if (full) hipLaunchKernelGGL((ac_decode_lean_kernel<4, true>), grid, block, 0, st, pack);
+        else hipLaunchKernelGGL((ac_decode_lean_kernel<4, false>), grid, block, 0, st, pack);
+        const int rc = l3c::check_launch("ac_decode_lean_kernel");
         if (rc != L3C_OK) return rc;
     }
     for (int i = 0; i < n_parts; ++i) pack.part[i].force = fast_pass ? 0 : 1;

@@ -35,5 +35,12 @@ for k in range(a.reps + 1):
 med = [statistics.median(x) * 1e3 for x in zip(*ts)]
 print('batch {}: forward {:.2f} ms | coder (intervals + phase 1 + phase 2) {:.2f} ms | to_bytes {:.2f} ms | total {:.2f} ms (serialised by the '
       'synchronisations between the stages) | {} bytes'.format(a.batch, med[0], med[1], med[2], med[3], sum(map(len, data))))
-dec, _ = bc.decode_batch(data)
-print('lossless', bool(torch.equal(dec.to(torch.uint8), img.to(torch.uint8))))
+td = []
+for k in range(4):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    dec, _ = bc.decode_batch(data)
+    torch.cuda.synchronize()
+    td.append(time.perf_counter() - t0)
+print('decode {:.2f} ms (median of 3 after a warm-up) | lossless {}'.format(statistics.median(td[1:]) * 1e3,
+                                                                            bool(torch.equal(dec.to(torch.uint8), img.to(torch.uint8)))))
