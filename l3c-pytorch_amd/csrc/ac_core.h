@@ -314,6 +314,28 @@ L3C_HD uint32_t record_from_pair(uint32_t low1, uint32_t not_high1) {
     return pack_record(low1, (uint32_t)n | ((uint32_t)m << 8));
 }
 
+// ---- the decoder's state in the same form (csrc/ac_kernels.hip: ac_decode_lean_kernel) ---------------------------------------
+// (low, nh = ~high, range = high - low).  t_lo / t_hi: the scaled table entries (span * cdf[x]) >> 16 and (span * cdf[x + 1]) >> 16
+// the symbol search has produced (low' = low + t_lo, high' = low - 1 + t_hi; the top symbol keeps high).  Returns c = n + m, the
+// number of stream bits to shift into `value`, and msb: 0x80000000 iff m > 0 -- the bit the underflow steps take out of low and
+// out of value:  ((value << n | bits_n) << m ^ 2^31) | bits_m  ==  (value << c | bits_c) ^ msb.
+L3C_HD int lean_advance(uint32_t &low, uint32_t &nh, uint32_t &range, uint32_t t_lo, uint32_t t_hi, bool top_symbol, uint32_t &msb) {
+    const uint32_t lo = low + t_lo;
+    const uint32_t nh1 = top_symbol ? nh : 0u - (low + t_hi);   // ~(low - 1 + t_hi)
+    const uint32_t h = ~((lo ^ nh1) | ((lo & nh1) << 1));        // role_shift: != 0 as lo < hi
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int c = __builtin_clz(h);
+#else
+    const int c = clz32(h) & 31;
+#endif
+    const uint32_t lo_s = lo << c;
+    msb = lo_s & 0x80000000u;
+    low = lo_s ^ msb;
+    nh = (nh1 << c) & 0x7FFFFFFFu;
+    range = ~(low + nh);
+    return c;
+}
+
 // Literal (serial) emission of one record -- the definition phase 2 must reproduce; also used for its rare long runs.
 template <class Sink>
 L3C_HD void emit_record(uint32_t rec_lo, uint32_t rec_nm, uint32_t &pending, Sink &sink) {

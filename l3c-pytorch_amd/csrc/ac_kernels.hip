@@ -6,10 +6,12 @@
 //                                 interval word is replaced in place by its role's bound after the update (low' / ~high')
 //   ac_pack_kernel                encoder phase 2, one stream per WAVEFRONT, 64 symbols per step: pending runs by a segmented
 //                                 wave scan, bit offsets by a prefix sum, bits merged with LDS atomics, words written coalesced
-//   ac_decode_ring_kernel         one stream per WAVEFRONT: the table streams through an LDS ring by LDS-DMA, lanes hold the CDF
-//                                 row of the current symbol; the symbol is ranked against the row with v_cmp + s_bcnt1
-//                                 (division-free) or, for tables not known to be monotone, with the reference's literal
-//                                 binary search over v_readlane; the coder state lives in SGPRs (wave-uniform)
+//   ac_decode_lean_kernel         the fast pass, one stream per WAVEFRONT: the table streams through an LDS ring by LDS-DMA,
+//                                 lanes hold the CDF row of the current symbol; the symbol is ranked against the scaled row
+//                                 with v_cmp + s_bcnt1 (division-free); the coder state lives in SGPRs (wave-uniform); full
+//                                 ring blocks of the 256-symbol alphabet run a hand-written, branch-free loop
+//   ac_decode_ring_kernel         the generic decoder on the same ring (streams the fast pass gave up on, tables not known
+//                                 to be monotone): the reference's literal binary search over v_readlane
 //   ac_decode_const_row_kernel    the same for one row shared by all symbols (the uniform prior of the coarsest scale)
 //   check_monotone_kernel         flags tables that are not strictly increasing (selects the decode path)
 #include <vector>
@@ -402,7 +404,7 @@ __device__ __forceinline__ uint32_t regs_rank(const Regs<1> &r, uint32_t bound) 
 __device__ __forceinline__ uint32_t regs_rank(const Regs<4> &r, uint32_t bound) {
     return (count_le(r.a, bound) + count_le(r.b, bound)) + (count_le(r.c, bound) + count_le(r.d, bound));
 }
-// Lanes holding real table entries (index <= top), as wave-uniform 64-bit masks: the FAST decoder ranks UNMASKED rows and
+// Lanes holding real table entries (index <= top), as wave-uniform 64-bit masks: the fast decoder ranks UNMASKED rows and
 // ands the ballots with these (a masked entry 0x10000 would scale to 2^32 = 0 when the interval is the full 32-bit range,
 // which recurs whenever a symbol's interval is an aligned power of two, e.g. a width-1 cdf step coded from the full range).
 template <int NJ>
@@ -424,13 +426,6 @@ __device__ __forceinline__ ValidLanes<4> valid_lanes4(int lane, int top) {
 }
 __device__ __forceinline__ uint32_t count_le_valid(uint32_t v, uint32_t bound, uint64_t valid) {
     return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(v <= bound) & valid);
-}
-__device__ __forceinline__ uint32_t regs_rank_valid(const Regs<1> &r, uint32_t bound, const ValidLanes<1> &v) {
-    return count_le_valid(r.a, bound, v.a);
-}
-__device__ __forceinline__ uint32_t regs_rank_valid(const Regs<4> &r, uint32_t bound, const ValidLanes<4> &v) {
-    return (count_le_valid(r.a, bound, v.a) + count_le_valid(r.b, bound, v.b)) +
-           (count_le_valid(r.c, bound, v.c) + count_le_valid(r.d, bound, v.d));
 }
 __device__ __forceinline__ uint32_t regs_fetch(const Regs<1> &r, uint32_t m) { return lane_read(r.a, m & 63u); }
 __device__ __forceinline__ uint32_t regs_fetch(const Regs<4> &r, uint32_t m) {   // m is wave-uniform
@@ -499,15 +494,27 @@ struct WaveBits {
         }
         return w;
     }
+    __device__ __forceinline__ void next_window() {   // the requested window becomes current, the one after it is requested
+        base += 64u;
+        if (age < 3u) vm_wait<0>();
+        cur = pick_up(base);
+        request(base + 64u);
+    }
     // word `idx` of the stream; idx never decreases and grows by at most one window between calls
     __device__ __forceinline__ uint32_t word(uint32_t idx) {
-        if (__builtin_expect(idx - base >= 64u, 0)) {   // window exhausted (wave-uniform, once per 64 words)
-            base += 64u;
-            if (age < 3u) vm_wait<0>();
-            cur = pick_up(base);
-            request(base + 64u);
-        }
+        if (__builtin_expect(idx - base >= 64u, 0)) next_window();   // window exhausted (wave-uniform, once per 64 words)
         return lane_read(cur, idx - base);
+    }
+    // lane l: word base + 32 + l of the stream -- the second half of the current window and the first half of the requested one
+    __device__ __forceinline__ uint32_t late_window() {
+        if (age < 3u) {
+            vm_wait<0>();
+            age = 3u;
+        }
+        const uint32_t nxt = pick_up(base + 64u);
+        const uint32_t a = (uint32_t)__builtin_amdgcn_ds_bpermute((lane + 32) * 4, (int)cur);    // lanes 0..31: cur[32 + l]
+        const uint32_t b = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 32) * 4, (int)nxt);    // lanes 32..63: nxt[l - 32]
+        return lane < 32 ? a : b;
     }
     // pos0: where a previous chunk of the same stream stopped (0 = start of the stream)
     __device__ __forceinline__ void init(const uint32_t *w, uint32_t n, int lane_, uint32_t lds_addr, uint32_t pos0 = 0) {
@@ -594,75 +601,7 @@ __device__ __forceinline__ uint32_t decode_symbol(const Regs<NJ> &row, uint32_t 
     return x;
 }
 
-// The fast path alone, for the FAST instantiation of the ring decoder (nothing but this in its loop).  Precondition:
-// validated (strictly increasing) table; `row16` holds the table entries SHIFTED LEFT BY 16 (lds_row_take_shifted), not
-// masked; `valid` marks the lanes that hold table entries.  With c16 = cdf << 16 the scaled entry (span * cdf) >> 16 is
-// the high half of c16 * span -- one v_mul_hi_u32 -- except for the full 32-bit range (span = 2^32), where it is c16
-// itself.  A renormalised interval of a validated table never collapses to one value (its width is >= 2^14), so the n == 32
-// case of renorm_counts cannot occur.  Returns false -- state untouched -- when value is outside [low, high], which a
-// stream of this coder / the reference never produces; the stream is then decoded again by the generic instantiation.
 __device__ __forceinline__ uint32_t mul_hi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-__device__ __forceinline__ Regs<1> regs_mul_hi(const Regs<1> &r, uint32_t s) { return Regs<1>{mul_hi(r.a, s)}; }
-__device__ __forceinline__ Regs<4> regs_mul_hi(const Regs<4> &r, uint32_t s) {
-    return Regs<4>{mul_hi(r.a, s), mul_hi(r.b, s), mul_hi(r.c, s), mul_hi(r.d, s)};
-}
-// entries x and x1 = x + 1 of a row: pick the register holding x once (wave-uniform selects), two v_readlanes; only when x is
-// the last lane of a register does x1 live in the next one
-__device__ __forceinline__ void regs_fetch2(const Regs<1> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
-    lo = lane_read(r.a, x & 63u);
-    hi = lane_read(r.a, x1 & 63u);
-}
-__device__ __forceinline__ void regs_fetch2(const Regs<4> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
-    const uint32_t j = x >> 6;
-    const uint32_t ab = j & 1u ? r.b : r.a, cd = j & 1u ? r.d : r.c;
-    const uint32_t sel = j & 2u ? cd : ab;
-    lo = lane_read(sel, x & 63u);
-    if (__builtin_expect((x1 & 63u) != 0u, 1)) {
-        hi = lane_read(sel, x1 & 63u);
-    } else {
-        const uint32_t j1 = x1 >> 6;   // 1..4; 4 (x == top == 255) is replaced by the caller
-        const uint32_t bc = j1 & 1u ? r.b : r.c;
-        hi = lane_read(j1 == 3u ? r.d : bc, 0u);
-    }
-}
-
-template <int NJ>
-__device__ __forceinline__ bool decode_symbol_fast(const Regs<NJ> &row16, const ValidLanes<NJ> &valid, uint32_t &low,
-                                                   uint32_t &high, uint32_t &value, WaveBits &src, int top, bool advance,
-                                                   uint32_t &x) {
-    const uint32_t range = high - low, d = value - low;
-    if (__builtin_expect(d > range, 0)) return false;
-    Regs<NJ> t;
-    if (__builtin_expect(range != 0xFFFFFFFFu, 1)) t = regs_mul_hi(row16, range + 1u);
-    else t = row16;
-    const uint32_t rank = regs_rank_valid(t, d, valid);
-    uint32_t x1 = rank > 1u ? rank : 1u;   // x + 1
-    asm("" : "+s"(x1));                    // keep it scalar: max - 1 would be canonicalised to a VALU-only saturating subtract
-    x = x1 - 1u;
-    if (advance) {
-        uint32_t t_lo, t_hi;
-        regs_fetch2(t, x, x1, t_lo, t_hi);   // x == top: t_hi is not a table entry, replaced below
-        uint32_t lo = low + t_lo;
-        uint32_t hi = x == (uint32_t)top ? high : low - 1u + t_hi;
-        // renorm_counts without its n == 32 case (lo != hi here) and without branches: after the common prefix is shifted out
-        // lo starts with 0 and hi with 1, so the underflow step is the identity for m == 0.
-        const int n = l3c::clz32(lo ^ hi);
-        lo <<= n;
-        hi = ~(~hi << n);
-        const int m = l3c::clz32(~((lo & ~hi) << 1));
-        low = (lo << m) & 0x7FFFFFFFu;
-        high = ~(~hi << m) | 0x80000000u;
-        const int c = n + m;
-        if (__builtin_expect(c <= 32, 1)) {   // ((value << n | bits_n) << m ^ msb) | bits_m  ==  (value << c | bits_c) ^ msb
-            value = src.shift_in(value, c) ^ (m ? 0x80000000u : 0u);
-        } else {   // n <= 18 here, m <= 31
-            value = src.shift_in(value, n);
-            value = src.shift_in(value, m) ^ 0x80000000u;
-        }
-    }
-    return true;
-}
-
 // lane (i & 63) keeps symbol i until the 64-symbol block is stored with one coalesced write
 __device__ __forceinline__ void keep_symbol(int16_t *dst, uint32_t i, uint32_t n_sym, uint32_t x, int lane, int &kept) {
     if ((int)(i & 63u) == lane) kept = (int)x;   // (v_writelane_b32 would need two SGPR operands: over gfx9's constant-bus limit)
@@ -773,20 +712,9 @@ struct DecodeArgs {
     int64_t sym_stride, sym_offset;   // stream s writes sym_out[s * sym_stride + sym_offset + i]
 };
 
-// The same with the entries shifted into the upper half-word (what decode_symbol_fast multiplies with).
-__device__ __forceinline__ void lds_row_take_shifted(Regs<1> &row, const Regs<1> &pending) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %0, 16, %1" : "=&v"(row.a) : "v"(pending.a));
-}
-__device__ __forceinline__ void lds_row_take_shifted(Regs<4> &row, const Regs<4> &pending) {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\tv_lshlrev_b32 %0, 16, %4\n\tv_lshlrev_b32 %1, 16, %5\n\tv_lshlrev_b32 %2, 16, %6\n\t"
-                 "v_lshlrev_b32 %3, 16, %7"
-                 : "=&v"(row.a), "=&v"(row.b), "=&v"(row.c), "=&v"(row.d)
-                 : "v"(pending.a), "v"(pending.b), "v"(pending.c), "v"(pending.d));
-}
-
-// FAST = true: the loop holds only decode_symbol_fast; a stream that leaves the fast path is marked by the sentinel -1 in the
-// chunk's first output symbol and abandoned (state_out untouched).  FAST = false: the generic decoder, run afterwards for
-// marked streams only, or for every stream when the table is not validated.
+// The GENERIC decoder: the reference's arithmetic literally (decode_symbol), for every stream when the table is not validated,
+// otherwise only for the streams the fast pass (ac_decode_lean_kernel, below) has marked by the sentinel -1 in the chunk's
+// first output symbol (state_out untouched) -- streams whose value left [low, high], which this coder never writes.
 // Up to 8 independent decode calls in one launch (blockIdx.y selects the part): the chunk-pipelined RGB decode runs the R, G
 // and B chunks of one pipeline step side by side without relying on several HIP streams reaching distinct hardware queues.
 struct DecodeArgsPack {
@@ -794,7 +722,7 @@ struct DecodeArgsPack {
     DecodeArgs part[N];
 };
 
-template <int NJ, bool FAST, int IPB_ = (NJ == 1 ? 3 : 9)>
+template <int NJ, int IPB_ = (NJ == 1 ? 3 : 9)>
 __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack pack) {
     using C = RingCfg<NJ, IPB_>;
     const DecodeArgs &a = pack.part[blockIdx.y];
@@ -815,11 +743,7 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
     const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
     int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
-    if (FAST && !validated) {   // not a table for the fast path: leave the whole chunk to the generic pass
-        if (lane == 0) dst[0] = (int16_t)-1;
-        return;
-    }
-    if (!FAST && !a.force && validated && dst[0] != (int16_t)-1) return;   // decoded by the FAST pass
+    if (!a.force && validated && dst[0] != (int16_t)-1) return;   // decoded by the fast pass (ac_decode_lean_kernel)
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
 
     auto request_block = [&](uint32_t k) {   // DMA the 16-byte granules holding rows [kR, (k+1)R) into slot k % NB
@@ -860,14 +784,10 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
 
     Regs<NJ> row, pending;
     lds_row_issue(block_addr(0), pending);
-    if (FAST) lds_row_take_shifted(row, pending);
-    else lds_row_take(row, pending);
+    lds_row_take(row, pending);
 
     int kept = 0;
     uint32_t i = 0;
-    ValidLanes<NJ> valid;
-    if constexpr (NJ == 1) valid = valid_lanes1(lane, top);
-    else valid = valid_lanes4(lane, top);
     for (uint32_t k = 0; k < n_blocks; ++k) {
         // Request block k + NB - 1 (its slot held block k - 1, fully consumed), then make sure block k + 1 -- whose first row
         // is prefetched at the end of this block -- has landed: only the two newest requests may stay in flight.
@@ -883,32 +803,21 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
         const uint32_t addr_cross = block_addr(k + 1u);
         uint32_t addr_next = block_addr(k) + (i - k * R + 1u) * row_bytes;
         for (; i < i_end; ++i) {
-            if (!FAST) regs_mask(row, lane, top);
+            regs_mask(row, lane, top);
             lds_row_issue(i == i_cross ? addr_cross : addr_next, pending);   // row i + 1 (past the end: never used)
             addr_next += row_bytes;
-            uint32_t x = 0;
-            bool ok = true;
-            if (FAST)
-                ok = decode_symbol_fast<NJ>(row, valid, low, high, value, src, top, i != no_advance, x);
-            else
-                x = decode_symbol<NJ>(row, low, high, value, src, top, validated, i != no_advance);
+            const uint32_t x = decode_symbol<NJ>(row, low, high, value, src, top, validated, i != no_advance);
             keep_symbol(dst, i, n_sym, x, lane, kept);
-            if (FAST) lds_row_take_shifted(row, pending);   // the only take of the loop, on every path
-            else lds_row_take(row, pending);                // (tools/check_asm_prefetch.py)
-            if (FAST && __builtin_expect(!ok, 0)) {
-                vm_wait<0>();
-                if (lane == 0) dst[0] = (int16_t)-1;   // same lane, after any block store: the last write to dst[0]
-                return;
-            }
+            lds_row_take(row, pending);   // the only take of the loop, on every path (tools/check_asm_prefetch.py)
         }
     }
     if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.pos, {0u, 0u, 0u, 0u}};
 }
 
 // ---- the lean fast decoder (round 4) --------------------------------------------------------------------------------------
-// What the FAST ring decoder above spends on a symbol is ~130 instructions, and a lone wavefront issues one every ~5 cycles
-// whatever they are: the chain costs its instruction COUNT.  Same ring, same arithmetic, same DecodeState between chunks,
-// ~40 % fewer instructions per symbol:
+// The fast pass over validated tables.  Round 3's version of it (the generic loop above with a division-free symbol) spent
+// ~130 instructions on a symbol, and a lone wavefront issues one every ~4 cycles whatever they are: the chain costs its
+// instruction COUNT.  Same ring, same arithmetic, same DecodeState between chunks, ~40 % fewer instructions per symbol:
 //   * rows land in the HIGH half-words of two alternating register sets (ds_read_u16_d16_hi; the low halves are zero and
 //     stay zero): no shift, no copy out of a staging set; the loop is unrolled by two rows
 //   * the state is (low, ~high, range) as in the encoder's lane pairs (csrc/ac_core.h): ONE count n + m renormalises both
@@ -958,6 +867,8 @@ __device__ __forceinline__ uint32_t row_rank(const RowHi<4> &t, uint32_t d, cons
     if (ALLVALID) return (count_le(t.a, d) + count_le(t.b, d)) + (count_le(t.c, d) + count_le(t.d, d));
     return (count_le_valid(t.a, d, v.a) + count_le_valid(t.b, d, v.b)) + (count_le_valid(t.c, d, v.c) + count_le_valid(t.d, d, v.d));
 }
+// entries x and x1 = x + 1 of a row: pick the register holding x once (wave-uniform selects), two v_readlanes; only when x is
+// the last lane of a register does x1 live in the next one
 __device__ __forceinline__ void row_fetch2(const RowHi<1> &r, uint32_t x, uint32_t x1, uint32_t &lo, uint32_t &hi) {
     lo = lane_read(r.a, x & 63u);
     hi = lane_read(r.a, x1 & 63u);
@@ -1002,16 +913,8 @@ __device__ __forceinline__ void lean_symbol_body(const RowHi<NJ> &row, const Val
     x = x1 - 1u;
     row_fetch2(t, x, x1, t_lo, t_hi);
     if (advance) {   // x == top: t_hi is not a table entry, replaced
-        const uint32_t lo = st.low + t_lo;
-        const uint32_t nh1 = x == top ? st.nh : 0u - (st.low + t_hi);   // ~(low - 1 + t_hi); the top symbol keeps high
-        // csrc/ac_core.h, role_shift: n + m = clz of (lo ^ hi) & ~((lo & ~hi) << 1); <= 31, and != 0 as lo < hi
-        const uint32_t h = ~((lo ^ nh1) | ((lo & nh1) << 1));
-        const int c = __builtin_clz(h);
-        const uint32_t lo_s = lo << c;
-        const uint32_t msb = lo_s & 0x80000000u;   // set iff m > 0: the bit the underflow steps take out of low and value
-        st.low = lo_s ^ msb;
-        st.nh = (nh1 << c) & 0x7FFFFFFFu;
-        st.range = ~(st.low + st.nh);
+        uint32_t msb;
+        const int c = l3c::lean_advance(st.low, st.nh, st.range, t_lo, t_hi, x == top, msb);
         // ((value << n | bits_n) << m ^ msb) | bits_m  ==  (value << c | bits_c) ^ msb
         st.vb = (((st.vb & 0xFFFFFFFF00000000ull) | (st.buf >> 32)) << c) ^ ((uint64_t)msb << 32);
         st.buf <<= c;
@@ -1041,7 +944,7 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
 // the compares on one vcc: 290 ns.  Here a symbol is 66 instructions WITHOUT A BRANCH:
 //   * the conditions that need other code are only RECORDED -- value outside [low, high] (bad), the interval being the whole
 //     32-bit range at a symbol (minspan == 0: span = range + 1 wraps) -- and the caller decodes the block again from the saved
-//     state with lean_symbol if one was; the bit window cannot run out inside a block (the caller checks: <= 1 word a symbol)
+//     state with lean_symbol if one was; the caller hands over a bit window that cannot run out inside the block
 //   * the register holding entry x (and the one holding x + 1) is picked by VGPR indexing (s_set_gpr_idx_on over v96..v100,
 //     fixed registers so that they are consecutive) instead of scalar tests, v_cndmask and the hand-over back
 //   * the refill of the bit buffer is arithmetic: the word is read every symbol (v_readlane, off the chain) and or-ed in as
@@ -1053,16 +956,16 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
 #define L3C_ROW_READS(R0, R1, R2, R3, ADDR)                                                                        \
     "ds_read_u16_d16_hi " R0 ", " ADDR "\n\tds_read_u16_d16_hi " R1 ", " ADDR " offset:128\n\t"                     \
     "ds_read_u16_d16_hi " R2 ", " ADDR " offset:256\n\tds_read_u16_d16_hi " R3 ", " ADDR " offset:384\n\t"
-#define L3C_SYMBOL(R0, R1, R2, R3, SET_M0_TO_ROW)                                                                   \
+// PREFETCH: the reads of the NEXT row (other register set) and whatever else does not depend on this symbol, placed where
+// the scalar unit waits for the compares.  BETWEEN: independent scalar work placed where it waits for the v_readlanes.
+#define L3C_SYMBOL(R0, R1, R2, R3, PREFETCH, SET_M0_TO_ROW, BETWEEN)                                                \
     "s_add_u32 %[span], %[range], 1\n\t"                                                                            \
-    "s_min_u32 %[minspan], %[minspan], %[span]\n\t"                                                                 \
     "s_sub_u32 %[d], s97, %[low]\n\t"                      /* d = value - low */                                    \
-    "s_sub_u32 %[t0], %[range], %[d]\n\t"                  /* SCC = d > range */                                    \
-    "s_addc_u32 %[bad], %[bad], 0\n\t"                                                                              \
     "v_mul_hi_u32 v96, " R0 ", %[span]\n\tv_mul_hi_u32 v97, " R1 ", %[span]\n\t"                                    \
     "v_mul_hi_u32 v98, " R2 ", %[span]\n\tv_mul_hi_u32 v99, " R3 ", %[span]\n\t"                                    \
     "v_cmp_ge_u32_e64 %[m0], %[d], v96\n\tv_cmp_ge_u32_e64 %[m1], %[d], v97\n\t"                                    \
     "v_cmp_ge_u32_e64 %[m2], %[d], v98\n\tv_cmp_ge_u32_e64 %[m3], %[d], v99\n\t"                                    \
+    PREFETCH                                                                                                        \
     "s_bcnt1_i32_b64 %[r0], %[m0]\n\ts_bcnt1_i32_b64 %[r1], %[m1]\n\t"                                              \
     "s_bcnt1_i32_b64 %[r2], %[m2]\n\ts_bcnt1_i32_b64 %[r3], %[m3]\n\t"                                              \
     "s_add_i32 %[r0], %[r0], %[r1]\n\ts_add_i32 %[r2], %[r2], %[r3]\n\ts_add_i32 %[r0], %[r0], %[r2]\n\t"           \
@@ -1071,10 +974,14 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
     "s_set_gpr_idx_on %[r1], 1\n\tv_mov_b32 %[sel], v96\n\t"      /* the register of entry x ...      */            \
     "s_set_gpr_idx_idx %[r2]\n\tv_mov_b32 %[sel1], v96\n\t"       /* ... and of entry x + 1 (v100: x == top, replaced) */ \
     "s_set_gpr_idx_off\n\t"                                                                                         \
-    "v_readlane_b32 %[lo], %[sel], %[x]\n\tv_readlane_b32 %[hi], %[sel1], %[x1]\n\t"                                \
     SET_M0_TO_ROW "\n\t"                                                                                            \
+    "v_readlane_b32 %[lo], %[sel], %[x]\n\tv_readlane_b32 %[hi], %[sel1], %[x1]\n\t"                                \
     "v_readlane_b32 %[w], %[cur], %[wrel]\n\t"             /* the next stream word, whether needed or not */         \
     "v_writelane_b32 %[kept], %[x], m0\n\t"                                                                         \
+    "s_min_u32 %[minspan], %[minspan], %[span]\n\t"                                                                 \
+    "s_sub_u32 %[t0], %[range], %[d]\n\t"                  /* SCC = d > range */                                    \
+    "s_addc_u32 %[bad], %[bad], 0\n\t"                                                                              \
+    BETWEEN                                                                                                         \
     "s_add_u32 %[lo], %[lo], %[low]\n\t"                   /* low' */                                               \
     "s_add_u32 %[hi], %[hi], %[low]\n\ts_sub_u32 %[hi], 0, %[hi]\n\t"      /* ~high' = -(low + t_hi) */             \
     "s_cmp_eq_u32 %[x], %[top]\n\ts_cselect_b32 %[hi], %[nh], %[hi]\n\t"   /* the top symbol keeps high */           \
@@ -1098,17 +1005,18 @@ __device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, LeanSta
     asm volatile(
         "s_mov_b32 s97, %[value]\n\ts_mov_b64 s[98:99], %[buf]\n\ts_mov_b32 s101, 0\n"
         "1:\n\t"
-        L3C_ROW_READS("%[b0]", "%[b1]", "%[b2]", "%[b3]", "%[addr]")
-        "v_add_u32 %[addr], %[rowb], %[addr]\n\t"
-        L3C_SYMBOL("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "s_mov_b32 m0, %[j]")
+        L3C_SYMBOL("%[a0]", "%[a1]", "%[a2_]", "%[a3]",
+                   L3C_ROW_READS("%[b0]", "%[b1]", "%[b2]", "%[b3]", "%[addr]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t",
+                   "s_mov_b32 m0, %[j]",
+                   // the row after the block's last lives in the next block
+                   "s_add_u32 %[t0], %[j], 2\n\ts_cmp_eq_u32 %[t0], %[R]\n\ts_cselect_b64 vcc, -1, 0\n\t"
+                   "v_cndmask_b32 %[a2], %[addr], %[across], vcc\n\t")
         "s_waitcnt lgkmcnt(0)\n\t"
-        "s_add_u32 %[t0], %[j], 2\n\ts_cmp_eq_u32 %[t0], %[R]\n\ts_cselect_b64 vcc, -1, 0\n\t"
-        "v_cndmask_b32 %[a2], %[addr], %[across], vcc\n\t"      // the row after the block's last lives in the next block
-        L3C_ROW_READS("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "%[a2]")
-        "v_add_u32 %[addr], %[rowb], %[addr]\n\t"
-        L3C_SYMBOL("%[b0]", "%[b1]", "%[b2]", "%[b3]", "s_add_u32 m0, %[j], 1")
+        L3C_SYMBOL("%[b0]", "%[b1]", "%[b2]", "%[b3]",
+                   L3C_ROW_READS("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "%[a2]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t",
+                   "s_add_u32 m0, %[j], 1", "s_add_u32 %[j], %[j], 2\n\t")
         "s_waitcnt lgkmcnt(0)\n\t"
-        "s_add_u32 %[j], %[j], 2\n\ts_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
+        "s_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
         "s_mov_b32 %[value], s97\n\ts_mov_b64 %[buf], s[98:99]"
         : [a0] "+v"(A.a), [a1] "+v"(A.b), [a2_] "+v"(A.c), [a3] "+v"(A.d), [b0] "+v"(B.a), [b1] "+v"(B.b), [b2] "+v"(B.c),
           [b3] "+v"(B.d), [kept] "+v"(kept), [addr] "+v"(addr_next), [low] "+s"(st.low), [nh] "+s"(st.nh), [range] "+s"(st.range),
@@ -1163,6 +1071,21 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
     auto request_block = [&](uint32_t k) {   // DMA the 16-byte granules holding rows [kR, (k+1)R) into slot k % NB
         const uint64_t a = (stream0 + (uint64_t)k * R * row_bytes) & ~(uint64_t)15;
         uint8_t *slot = ring + (k % C::NB) * C::BLOCK_BYTES;
+        if (a + (uint64_t)(C::IPB * 1024 - 16) <= last_granule) {
+            // the whole block lies inside the table (all but the last blocks of the last stream): one address per 4 KB, the
+            // 1 KB steps as the instruction's immediate offset, which moves the global and the LDS address alike
+#pragma unroll
+            for (int q0 = 0; q0 < C::IPB; q0 += 4) {
+                const uint64_t g = a + (uint64_t)(q0 * 1024 + lane * 16);
+                const auto gp = (const __attribute__((address_space(1))) void *)g;
+                const auto lp = (__attribute__((address_space(3))) void *)(slot + q0 * 1024);
+                __builtin_amdgcn_global_load_lds(gp, lp, 16, 0, 0);
+                if (q0 + 1 < C::IPB) __builtin_amdgcn_global_load_lds(gp, lp, 16, 1024, 0);
+                if (q0 + 2 < C::IPB) __builtin_amdgcn_global_load_lds(gp, lp, 16, 2048, 0);
+                if (q0 + 3 < C::IPB) __builtin_amdgcn_global_load_lds(gp, lp, 16, 3072, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < C::IPB; ++q) {
             uint64_t g = a + (uint64_t)(q * 1024 + lane * 16);
@@ -1251,11 +1174,20 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
         bool done = false;
         if constexpr (NJ == 4 && ALLVALID) {
             // the hand-written loop, unless the bit window could run out inside the block (a symbol takes at most one word)
-            if (full_block && st.widx - src.base + R < 64u) {
+            if (full_block) {
+                // the bit window: a block takes at most R <= 32 words (one a symbol).  Window indices stay below 64 if the block
+                // starts below 32; otherwise it reads a window that starts 32 words later (late_window)
+                if (st.widx - src.base >= 64u) src.next_window();
+                uint32_t wrel = st.widx - src.base, wofs = 0u, window = src.cur;
+                if (wrel >= 32u) {
+                    window = src.late_window();
+                    wofs = 32u;
+                    wrel -= 32u;
+                }
                 const LeanState saved = st;
-                uint32_t wrel = st.widx - src.base, minspan = 0xFFFFFFFFu;
-                lean_block_asm(rowA, rowB, st, wrel, minspan, src.cur, kept, addr_next, addr_cross, row_bytes, R, top);
-                st.widx = src.base + wrel;
+                uint32_t minspan = 0xFFFFFFFFu;
+                lean_block_asm(rowA, rowB, st, wrel, minspan, window, kept, addr_next, addr_cross, row_bytes, R, top);
+                st.widx = src.base + wofs + wrel;
                 done = minspan != 0u && st.bad == 0u;
                 if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range or a bad value: again, the careful way
                     st = saved;
@@ -1349,9 +1281,9 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
         if (rc != L3C_OK) return rc;
     }
     for (int i = 0; i < n_parts; ++i) pack.part[i].force = fast_pass ? 0 : 1;
-    if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1, false>), grid, block, 0, st, pack);
-    else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, false, 3>), grid, block, 0, st, pack);
-    else hipLaunchKernelGGL((ac_decode_ring_kernel<4, false>), grid, block, 0, st, pack);
+    if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1>), grid, block, 0, st, pack);
+    else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, 3>), grid, block, 0, st, pack);
+    else hipLaunchKernelGGL((ac_decode_ring_kernel<4>), grid, block, 0, st, pack);
     return l3c::check_launch("ac_decode_ring_kernel<generic>");
 }
 

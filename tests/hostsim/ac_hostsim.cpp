@@ -76,6 +76,27 @@ void hostsim_decode(const uint16_t *cdf, long long row_stride, int Lp, const uin
     uint32_t low = 0, high = 0xFFFFFFFFu;
     uint32_t value = src.take(32);
     const uint32_t top = (uint32_t)(Lp - 2);
+    if (monotone == 3) {   // the lean fast decoder's state machine (ac_decode_lean_kernel): (low, ~high, range), one count n + m
+        uint32_t nh = 0u, range = 0xFFFFFFFFu;
+        for (long long i = 0; i < N; ++i) {
+            const uint16_t *row = cdf + i * row_stride;
+            const uint32_t d = value - low;
+            if (d > range) {   // outside [low, high]: the kernel hands such a stream to the generic decoder
+                for (long long j = i; j < N; ++j) sym_out[j] = -1;
+                return;
+            }
+            auto scaled = [&](uint32_t c) { return (uint32_t)(((uint64_t)range * c + c) >> 16); };
+            uint32_t rank = 0;
+            for (uint32_t m = 0; m <= top; ++m) rank += scaled(row[m]) <= d;
+            const uint32_t x = rank ? rank - 1 : 0;
+            sym_out[i] = (int16_t)x;
+            if (i == N - 1) break;
+            uint32_t msb;
+            const int c = l3c::lean_advance(low, nh, range, scaled(row[x]), x == top ? 0u : scaled(row[x + 1]), x == top, msb);
+            value = (c ? ((value << c) | src.take(c)) : value) ^ msb;
+        }
+        return;
+    }
     for (long long i = 0; i < N; ++i) {
         const uint16_t *row = cdf + i * row_stride;
         const uint32_t count = l3c::decode_count(low, high, value);

@@ -19,6 +19,7 @@ def test_hostsim_kats(golden):
         assert hs.encode(tab, sym, fast=False) == ref, n
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), n
         assert (hs.decode(tab, ref, len(sym), 2) == sym).all(), n
+        assert (hs.decode(tab, ref, len(sym), 3) == sym).all(), (n, 'lean')
         assert (hs.decode(tab, ref, len(sym), False) == sym).all(), n
 
 
@@ -63,6 +64,7 @@ def test_hostsim_random_vs_oracle():
         assert hs.encode(tab, sym, fast=False) == ref, it
         assert (hs.decode(tab, ref, len(sym), True) == sym).all(), it
         assert (hs.decode(tab, ref, len(sym), 2) == sym).all(), it
+        assert (hs.decode(tab, ref, len(sym), 3) == sym).all(), (it, 'lean')
         assert (hs.decode(tab, junk_probe(rng), len(sym), 2) == ac.decode(tab, _last_junk[0])).all(), ('junk2', it)
         assert (hs.decode(tab, ref, len(sym), False) == sym).all(), it
         junk = rng.randint(0, 256, size=rng.randint(0, 200)).astype(np.uint8).tobytes()
@@ -80,10 +82,23 @@ def test_hostsim_degenerate_intervals():
         sym = np.full(N, s, dtype=np.int16)
         ref = ac.encode(tab, sym)
         assert hs.encode(tab, sym) == ref and hs.encode(tab, sym, fast=2) == ref
-        assert (hs.decode(tab, ref, N, True) == sym).all()
+        assert (hs.decode(tab, ref, N, True) == sym).all() and (hs.decode(tab, ref, N, 3) == sym).all()
     tab[:, 1] = 32768
     tab[:, 2] = 32769
     sym = np.tile(np.array([0, 2, 1, 1, 2, 0], dtype=np.int16), N // 6)
     ref = ac.encode(tab, sym)
     assert hs.encode(tab, sym) == ref and hs.encode(tab, sym, fast=False) == ref and hs.encode(tab, sym, fast=2) == ref
     assert (hs.decode(tab, ref, N, False) == sym).all()
+
+
+def test_hostsim_dyadic_table_meets_the_full_range_again():
+    """A uniform 256-symbol table (entries = multiples of 256): every interval is an aligned power of two, so the coder is back at
+    the full 32-bit range (span = 2^32) after every symbol -- the case the lane-pair encoder carries as range = 2^32 - 1 and the
+    lean decoder as its own instantiation."""
+    rng = np.random.RandomState(3)
+    N = 4000
+    tab = np.tile((np.arange(257) * 256).astype(np.int64).astype(np.uint16), (N, 1))
+    sym = rng.randint(0, 256, size=N).astype(np.int16)
+    ref = ac.encode(tab, sym)
+    assert hs.encode(tab, sym, fast=2) == ref and hs.encode(tab, sym, fast=True) == ref
+    assert (hs.decode(tab, ref, N, 3) == sym).all() and (hs.decode(tab, ref, N, 2) == sym).all()

@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Build-time check for the ring decoder's software-pipelined LDS reads (csrc/ac_kernels.hip: lds_row_issue / lds_row_take).
+"""Build-time check for the decoders' software-pipelined LDS reads (csrc/ac_kernels.hip: lds_row_issue / lds_row_take of the
+generic ring decoder, row_hi_issue / row_hi_wait of the lean one).
 
-The rows are fetched by inline-asm ds_read_u16 whose completion the compiler knows nothing about, so the registers they
-target must not be touched by compiler-generated code between the issue and the take (which waits for lgkmcnt(0) and moves
-the values out).  This script compiles the kernels to ISA, rebuilds the control-flow graph of every ac_decode_ring_kernel
-instantiation, propagates the state "reads in flight" (set by an asm block with ds_read_u16, cleared by an asm block with
-s_waitcnt lgkmcnt(0)) and verifies that no instruction outside inline asm names one of the target registers while reads may
-be in flight.
+The rows are fetched by inline-asm ds_read_u16 / ds_read_u16_d16_hi whose completion the compiler knows nothing about, so the
+registers they target must not be touched by compiler-generated code between the issue and the wait (s_waitcnt lgkmcnt(0) in an
+asm block).  This script compiles the kernels to ISA, rebuilds the control-flow graph of every ac_decode_ring_kernel and
+ac_decode_lean_kernel instantiation, propagates the state "reads in flight" (set by an asm block with such a read, cleared by
+an asm block with s_waitcnt lgkmcnt(0) -- the hand-written block loop of the lean decoder is one asm block that ends waited)
+and verifies that no instruction outside inline asm names one of the target registers while reads may be in flight.
 
     python tools/check_asm_prefetch.py        (exit status 0 = ok)
 """
@@ -96,7 +97,7 @@ def check_function(name, lines):
     def transfer(b, state, report=None):
         for kind, body in b['items']:
             if kind == 'asm':
-                dests = {int(m.group(1)) for l in body for m in [re.match(r'ds_read_u16 v(\d+),', l)] if m}
+                dests = {int(m.group(1)) for l in body for m in [re.match(r'ds_read_u16(?:_d16_hi)? v(\d+),', l)] if m}
                 if dests:
                     state = state | dests
                 if any('lgkmcnt(0)' in l for l in body):
@@ -131,9 +132,9 @@ def check_function(name, lines):
 
 def main():
     text = compile_isa()
-    funcs = [i for i, l in enumerate(text) if re.match(r'^_ZN.*ac_decode_ring_kernel.*:\s', l)]
-    if len(funcs) < 4:
-        print('expected 4 ring kernel instantiations, found', len(funcs))
+    funcs = [i for i, l in enumerate(text) if re.match(r'^_ZN.*ac_decode_(ring|lean)_kernel.*:\s', l)]
+    if len(funcs) != 8:
+        print('expected 3 generic + 5 lean decoder instantiations, found', len(funcs))
         return 1
     bad = 0
     for start in funcs:

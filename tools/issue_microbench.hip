@@ -26,7 +26,7 @@
         s3 = __builtin_amdgcn_readfirstlane(s3);                                   \
         for (int r = 0; r < reps; ++r) {                                           \
             asm volatile(".rept 256\n" BODY "\n.endr"                               \
-                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)::"vcc", "memory", "v100", "v101", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s90", "s91"); \
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3)::"vcc", "memory", "v100", "v101", "v102", "v103", "v104", "m0", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s90", "s91"); \
         }                                                                          \
         out[threadIdx.x] = a + b + c + d + s0 + s1 + s2 + s3;                      \
     }
@@ -59,6 +59,12 @@ KERNEL(k_s_to_v, "s_add_u32 %4, %4, 1\n v_add_u32 %0, %0, %4")                  
 KERNEL(k_cndmask_vcc, "s_cmp_lg_u32 %4, 0\n s_cselect_b64 vcc, -1, 0\n v_cndmask_b32 %0, %0, %1, vcc")
 KERNEL(k_branch_taken, "s_branch 0")   // s_branch to the next instruction (simm16 = 0): a taken branch
 KERNEL(k_branch_not_taken, "s_cmp_eq_u32 %4, %4\n s_cbranch_scc0 0")
+KERNEL(k_gpr_idx, "s_set_gpr_idx_on %4, 1\n v_mov_b32 %0, v100\n s_set_gpr_idx_off")
+KERNEL(k_gpr_idx2, "s_set_gpr_idx_on %4, 1\n v_mov_b32 %0, v100\n s_set_gpr_idx_idx %5\n v_mov_b32 %1, v100\n s_set_gpr_idx_off")
+KERNEL(k_sel_cndmask, "s_bitcmp0_b32 %4, 6\n s_cselect_b64 vcc, -1, 0\n s_bitcmp0_b32 %4, 7\n v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %2, %3, %2, vcc\n"
+                      "s_cselect_b64 vcc, -1, 0\n v_cndmask_b32 %0, %2, %0, vcc")
+KERNEL(k_readlane_x2_sadd, "v_readlane_b32 %5, %0, %4\n v_readlane_b32 %6, %1, %4\n s_add_u32 %4, %4, %5\n s_add_u32 %4, %4, %6")
+KERNEL(k_writelane_m0, "s_mov_b32 m0, %4\n v_readlane_b32 %5, %1, %4\n v_writelane_b32 %0, %4, m0")
 KERNEL(k_lds_chase, "ds_read_b32 %0, %0\n s_waitcnt lgkmcnt(0)")
 
 struct Test {
@@ -99,6 +105,11 @@ int main() {
         {"s_cmp, s_cselect vcc, v_cndmask chain", k_cndmask_vcc, 3},
         {"s_branch (taken, to the next instruction)", k_branch_taken, 1},
         {"s_cmp + s_cbranch not taken", k_branch_not_taken, 2},
+        {"s_set_gpr_idx_on, v_mov, s_set_gpr_idx_off", k_gpr_idx, 3},
+        {"s_set_gpr_idx_on, v_mov, s_set_gpr_idx_idx, v_mov, _off", k_gpr_idx2, 5},
+        {"register select by 2 s_bitcmp, 2 s_cselect, 3 v_cndmask", k_sel_cndmask, 7},
+        {"2 x v_readlane, then 2 x s_add reading them (chain)", k_readlane_x2_sadd, 4},
+        {"s_mov m0, v_readlane, v_writelane ... m0", k_writelane_m0, 3},
         {"ds_read_b32 pointer chase + wait", k_lds_chase, 2},
     };
     const int reps = 400;
