@@ -1,8 +1,8 @@
 /*
  * l3c_xcheck.h -- C ABI of libl3c_hip_xcheck.so, a TEST-ONLY library (csrc/build.py builds it next to the product library; the
  * product never loads it).  It holds the round-1/2 Winograd F(2x2,3x3) convolution kernel (csrc/conv_wino.hip), kept as an
- * independent second implementation the tests compare the product's F(4x4,3x3) kernel with (tests/test_gpu_conv.py), plus the
- * library-level entry points of l3c_api.hip (error text).  Same conventions as include/l3c_hip.h.
+ * independent second implementation the tests compare the product's F(4x4,3x3) kernel with (tests/test_gpu_conv.py), the exhaustive
+ * check of the head's sigmoid (csrc/xcheck_dmll.hip), plus the library-level entry points of l3c_api.hip (error text).  Same conventions as include/l3c_hip.h.
  */
 #ifndef L3C_XCHECK_H_
 #define L3C_XCHECK_H_
@@ -28,6 +28,13 @@ int64_t l3c_conv_wino_packed_words(int Cout, int Cin);
 int l3c_conv_wino_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
 int l3c_conv_wino(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 int l3c_conv_wino_set_tiles_per_block(int n);
+
+/*
+ * csrc/dmll_core.h: sigmoid_sat (what the kernels evaluate) against 1 / (1 + expf(-a)) (what it has to equal) on every one of
+ * the 2^32 float bit patterns.  *mismatches_dev (uint64, device, zeroed by the caller) += number of differing results,
+ * *first_bad_dev (uint32, device, 0xFFFFFFFF from the caller) = smallest differing bit pattern.
+ */
+int l3c_xcheck_sigmoid_exhaustive(unsigned long long *mismatches_dev, uint32_t *first_bad_dev, l3c_stream_t stream);
 
 #ifdef __cplusplus
 }

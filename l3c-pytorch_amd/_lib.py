@@ -104,6 +104,7 @@ XCHECK_PROTOTYPES = {
     'l3c_conv_wino_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_wino': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_wino_set_tiles_per_block': (c_int, [c_int]),
+    'l3c_xcheck_sigmoid_exhaustive': (c_int, [c_vp, c_vp, c_vp]),
 }
 XCHECK_LIB_PATH = os.path.join(_HERE, 'csrc', 'libl3c_hip_xcheck.so')
 

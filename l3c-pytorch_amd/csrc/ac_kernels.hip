@@ -956,26 +956,41 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
 #define L3C_ROW_READS(R0, R1, R2, R3, ADDR)                                                                        \
     "ds_read_u16_d16_hi " R0 ", " ADDR "\n\tds_read_u16_d16_hi " R1 ", " ADDR " offset:128\n\t"                     \
     "ds_read_u16_d16_hi " R2 ", " ADDR " offset:256\n\tds_read_u16_d16_hi " R3 ", " ADDR " offset:384\n\t"
-// PREFETCH: the reads of the NEXT row (other register set) and whatever else does not depend on this symbol, placed where
-// the scalar unit waits for the compares.  BETWEEN: independent scalar work placed where it waits for the v_readlanes.
-#define L3C_SYMBOL(R0, R1, R2, R3, PREFETCH, SET_M0_TO_ROW, BETWEEN)                                                \
+#define L3C_ROW_READ1(R0, ADDR) "ds_read_u16_d16_hi " R0 ", " ADDR "\n\t"
+// d = value - low; the scaled row; one compare per register into an SGPR pair of its own
+#define L3C_SYMBOL_SCALE4(R0, R1, R2, R3)                                                                          \
     "s_add_u32 %[span], %[range], 1\n\t"                                                                            \
-    "s_sub_u32 %[d], s97, %[low]\n\t"                      /* d = value - low */                                    \
+    "s_sub_u32 %[d], s97, %[low]\n\t"                                                                               \
     "v_mul_hi_u32 v96, " R0 ", %[span]\n\tv_mul_hi_u32 v97, " R1 ", %[span]\n\t"                                    \
     "v_mul_hi_u32 v98, " R2 ", %[span]\n\tv_mul_hi_u32 v99, " R3 ", %[span]\n\t"                                    \
     "v_cmp_ge_u32_e64 %[m0], %[d], v96\n\tv_cmp_ge_u32_e64 %[m1], %[d], v97\n\t"                                    \
-    "v_cmp_ge_u32_e64 %[m2], %[d], v98\n\tv_cmp_ge_u32_e64 %[m3], %[d], v99\n\t"                                    \
-    PREFETCH                                                                                                        \
+    "v_cmp_ge_u32_e64 %[m2], %[d], v98\n\tv_cmp_ge_u32_e64 %[m3], %[d], v99\n\t"
+#define L3C_SYMBOL_SCALE1(R0)                                                                                      \
+    "s_add_u32 %[span], %[range], 1\n\t"                                                                            \
+    "s_sub_u32 %[d], s97, %[low]\n\t"                                                                               \
+    "v_mul_hi_u32 v96, " R0 ", %[span]\n\t"                                                                         \
+    "v_cmp_ge_u32_e64 %[m0], %[d], v96\n\t"
+// x1 = max(rank, 1), x = x1 - 1, lo = t[x], hi = t[x1].  Four registers: the one holding entry x (and the one holding x + 1; v100
+// for x == top, replaced below) is picked by VGPR indexing
+#define L3C_SYMBOL_RANK4(SET_M0_TO_ROW)                                                                            \
     "s_bcnt1_i32_b64 %[r0], %[m0]\n\ts_bcnt1_i32_b64 %[r1], %[m1]\n\t"                                              \
     "s_bcnt1_i32_b64 %[r2], %[m2]\n\ts_bcnt1_i32_b64 %[r3], %[m3]\n\t"                                              \
     "s_add_i32 %[r0], %[r0], %[r1]\n\ts_add_i32 %[r2], %[r2], %[r3]\n\ts_add_i32 %[r0], %[r0], %[r2]\n\t"           \
     "s_max_u32 %[x1], %[r0], 1\n\ts_add_i32 %[x], %[x1], -1\n\t"                                                    \
     "s_lshr_b32 %[r1], %[x], 6\n\ts_lshr_b32 %[r2], %[x1], 6\n\t"                                                   \
-    "s_set_gpr_idx_on %[r1], 1\n\tv_mov_b32 %[sel], v96\n\t"      /* the register of entry x ...      */            \
-    "s_set_gpr_idx_idx %[r2]\n\tv_mov_b32 %[sel1], v96\n\t"       /* ... and of entry x + 1 (v100: x == top, replaced) */ \
+    "s_set_gpr_idx_on %[r1], 1\n\tv_mov_b32 %[sel], v96\n\t"                                                        \
+    "s_set_gpr_idx_idx %[r2]\n\tv_mov_b32 %[sel1], v96\n\t"                                                         \
     "s_set_gpr_idx_off\n\t"                                                                                         \
     SET_M0_TO_ROW "\n\t"                                                                                            \
-    "v_readlane_b32 %[lo], %[sel], %[x]\n\tv_readlane_b32 %[hi], %[sel1], %[x1]\n\t"                                \
+    "v_readlane_b32 %[lo], %[sel], %[x]\n\tv_readlane_b32 %[hi], %[sel1], %[x1]\n\t"
+#define L3C_SYMBOL_RANK1(SET_M0_TO_ROW)                                                                            \
+    "s_and_b64 %[m0], %[m0], %[valid]\n\t"                 /* lanes past the top symbol hold no table entries */      \
+    "s_bcnt1_i32_b64 %[r0], %[m0]\n\t"                                                                              \
+    "s_max_u32 %[x1], %[r0], 1\n\ts_add_i32 %[x], %[x1], -1\n\t"                                                    \
+    SET_M0_TO_ROW "\n\t"                                                                                            \
+    "v_readlane_b32 %[lo], v96, %[x]\n\tv_readlane_b32 %[hi], v96, %[x1]\n\t"
+// the interval update, the renormalisation, the bit buffer (see the list above)
+#define L3C_SYMBOL_ADVANCE(BETWEEN)                                                                                \
     "v_readlane_b32 %[w], %[cur], %[wrel]\n\t"             /* the next stream word, whether needed or not */         \
     "v_writelane_b32 %[kept], %[x], m0\n\t"                                                                         \
     "s_min_u32 %[minspan], %[minspan], %[span]\n\t"                                                                 \
@@ -995,38 +1010,24 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
     "s_cmp_lt_u32 %[nbits], 32\n\ts_cselect_b32 s100, %[w], 0\n\ts_cselect_b32 %[r3], 1, 0\n\t"                     \
     "s_sub_u32 %[r2], 32, %[nbits]\n\ts_lshl_b64 s[94:95], s[100:101], %[r2]\n\ts_or_b64 s[98:99], s[98:99], s[94:95]\n\t" \
     "s_lshl_b32 %[r2], %[r3], 5\n\ts_add_u32 %[nbits], %[nbits], %[r2]\n\ts_add_u32 %[wrel], %[wrel], %[r3]\n\t"
+// PREFETCH: the reads of the NEXT row (other register set) and whatever else does not depend on this symbol, placed where
+// the scalar unit waits for the compares.  BETWEEN: independent scalar work placed where it waits for the v_readlanes.
+#define L3C_SYMBOL(R0, R1, R2, R3, PREFETCH, SET_M0_TO_ROW, BETWEEN) \
+    L3C_SYMBOL_SCALE4(R0, R1, R2, R3) PREFETCH L3C_SYMBOL_RANK4(SET_M0_TO_ROW) L3C_SYMBOL_ADVANCE(BETWEEN)
+#define L3C_SYMBOL1(R0, PREFETCH, SET_M0_TO_ROW, BETWEEN) \
+    L3C_SYMBOL_SCALE1(R0) PREFETCH L3C_SYMBOL_RANK1(SET_M0_TO_ROW) L3C_SYMBOL_ADVANCE(BETWEEN)
+// the row after the block's last lives in the next block
+#define L3C_CROSS_SELECT \
+    "s_add_u32 %[t0], %[j], 2\n\ts_cmp_eq_u32 %[t0], %[R]\n\ts_cselect_b64 vcc, -1, 0\n\tv_cndmask_b32 %[a2], %[addr], %[across], vcc\n\t"
+#define L3C_BLOCK_STATE_OPERANDS                                                                                   \
+    [kept] "+v"(kept), [addr] "+v"(addr_next), [low] "+s"(st.low), [nh] "+s"(st.nh), [range] "+s"(st.range),         \
+    [nbits] "+s"(st.nbits), [wrel] "+s"(wrel), [bad] "+s"(st.bad), [minspan] "+s"(minspan), [j] "+s"(j), [value] "+s"(value), \
+    [buf] "+s"(st.buf), [span] "=&s"(span), [d] "=&s"(d), [t0] "=&s"(t0), [r0] "=&s"(r0), [r1] "=&s"(r1), [r2] "=&s"(r2), \
+    [r3] "=&s"(r3), [x] "=&s"(x), [x1] "=&s"(x1), [lo] "=&s"(lo), [hi] "=&s"(hi), [w] "=&s"(w), [c] "=&s"(c), [a2] "=&v"(a2)
+#define L3C_BLOCK_CLOBBERS "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "m0", "scc", "vcc", "memory"
 
-__device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, LeanState &st, uint32_t &wrel, uint32_t &minspan,
-                                               uint32_t window, int &kept, uint32_t addr_next, uint32_t addr_cross,
-                                               uint32_t row_bytes, uint32_t R, uint32_t top) {
-    uint64_t m0, m1, m2, m3;
-    uint32_t span, d, t0, r0, r1, r2, r3, x, x1, lo, hi, w, c, sel, sel1, a2;
-    uint32_t value = (uint32_t)(st.vb >> 32), j = 0;
-    asm volatile(
-        "s_mov_b32 s97, %[value]\n\ts_mov_b64 s[98:99], %[buf]\n\ts_mov_b32 s101, 0\n"
-        "1:\n\t"
-        L3C_SYMBOL("%[a0]", "%[a1]", "%[a2_]", "%[a3]",
-                   L3C_ROW_READS("%[b0]", "%[b1]", "%[b2]", "%[b3]", "%[addr]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t",
-                   "s_mov_b32 m0, %[j]",
-                   // the row after the block's last lives in the next block
-                   "s_add_u32 %[t0], %[j], 2\n\ts_cmp_eq_u32 %[t0], %[R]\n\ts_cselect_b64 vcc, -1, 0\n\t"
-                   "v_cndmask_b32 %[a2], %[addr], %[across], vcc\n\t")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        L3C_SYMBOL("%[b0]", "%[b1]", "%[b2]", "%[b3]",
-                   L3C_ROW_READS("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "%[a2]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t",
-                   "s_add_u32 m0, %[j], 1", "s_add_u32 %[j], %[j], 2\n\t")
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
-        "s_mov_b32 %[value], s97\n\ts_mov_b64 %[buf], s[98:99]"
-        : [a0] "+v"(A.a), [a1] "+v"(A.b), [a2_] "+v"(A.c), [a3] "+v"(A.d), [b0] "+v"(B.a), [b1] "+v"(B.b), [b2] "+v"(B.c),
-          [b3] "+v"(B.d), [kept] "+v"(kept), [addr] "+v"(addr_next), [low] "+s"(st.low), [nh] "+s"(st.nh), [range] "+s"(st.range),
-          [nbits] "+s"(st.nbits), [wrel] "+s"(wrel), [bad] "+s"(st.bad), [minspan] "+s"(minspan), [j] "+s"(j), [value] "+s"(value),
-          [buf] "+s"(st.buf), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [span] "=&s"(span), [d] "=&s"(d),
-          [t0] "=&s"(t0), [r0] "=&s"(r0), [r1] "=&s"(r1), [r2] "=&s"(r2), [r3] "=&s"(r3), [x] "=&s"(x), [x1] "=&s"(x1),
-          [lo] "=&s"(lo), [hi] "=&s"(hi), [w] "=&s"(w), [c] "=&s"(c), [sel] "=&v"(sel), [sel1] "=&v"(sel1), [a2] "=&v"(a2)
-        : [cur] "v"(window), [across] "v"(addr_cross), [rowb] "s"(row_bytes), [R] "s"(R), [top] "s"(top)
-        : "v96", "v97", "v98", "v99", "v100", "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "m0", "scc", "vcc", "memory");
-    // what an asm statement returns counts as divergent: say that the state is wave-uniform (it already sits in SGPRs)
+// what an asm statement returns counts as divergent: say that the state is wave-uniform (it already sits in SGPRs)
+__device__ __forceinline__ void lean_block_uniform(LeanState &st, uint32_t &wrel, uint32_t &minspan, uint32_t value) {
     st.low = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.low);
     st.nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.nh);
     st.range = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.range);
@@ -1039,6 +1040,57 @@ __device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, LeanSta
     const uint32_t bh = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(st.buf >> 32));
     st.buf = ((uint64_t)bh << 32) | bl;
     st.vb = (uint64_t)value << 32;
+}
+
+// ONE row register (alphabets of up to 64 symbols: the bottleneck scales): the same loop, one compare, the valid-lane mask
+__device__ __forceinline__ void lean_block_asm(RowHi<1> &A, RowHi<1> &B, const ValidLanes<1> &valid, LeanState &st, uint32_t &wrel,
+                                               uint32_t &minspan, uint32_t window, int &kept, uint32_t addr_next,
+                                               uint32_t addr_cross, uint32_t row_bytes, uint32_t R, uint32_t top) {
+    uint64_t m0;
+    uint32_t span, d, t0, r0, r1, r2, r3, x, x1, lo, hi, w, c, a2;
+    uint32_t value = (uint32_t)(st.vb >> 32), j = 0;
+    asm volatile(
+        "s_mov_b32 s97, %[value]\n\ts_mov_b64 s[98:99], %[buf]\n\ts_mov_b32 s101, 0\n"
+        "1:\n\t"
+        L3C_SYMBOL1("%[a0]", L3C_ROW_READ1("%[b0]", "%[addr]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t", "s_mov_b32 m0, %[j]",
+                    L3C_CROSS_SELECT)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        L3C_SYMBOL1("%[b0]", L3C_ROW_READ1("%[a0]", "%[a2]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t", "s_add_u32 m0, %[j], 1",
+                    "s_add_u32 %[j], %[j], 2\n\t")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[value], s97\n\ts_mov_b64 %[buf], s[98:99]"
+        : [a0] "+v"(A.a), [b0] "+v"(B.a), [m0] "=&s"(m0), L3C_BLOCK_STATE_OPERANDS
+        : [cur] "v"(window), [across] "v"(addr_cross), [rowb] "s"(row_bytes), [R] "s"(R), [top] "s"(top), [valid] "s"(valid.a)
+        : "v96", L3C_BLOCK_CLOBBERS);
+    lean_block_uniform(st, wrel, minspan, value);
+}
+
+__device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, const ValidLanes<4> &, LeanState &st, uint32_t &wrel,
+                                               uint32_t &minspan, uint32_t window, int &kept, uint32_t addr_next,
+                                               uint32_t addr_cross, uint32_t row_bytes, uint32_t R, uint32_t top) {
+    uint64_t m0, m1, m2, m3;
+    uint32_t span, d, t0, r0, r1, r2, r3, x, x1, lo, hi, w, c, sel, sel1, a2;
+    uint32_t value = (uint32_t)(st.vb >> 32), j = 0;
+    asm volatile(
+        "s_mov_b32 s97, %[value]\n\ts_mov_b64 s[98:99], %[buf]\n\ts_mov_b32 s101, 0\n"
+        "1:\n\t"
+        L3C_SYMBOL("%[a0]", "%[a1]", "%[a2_]", "%[a3]",
+                   L3C_ROW_READS("%[b0]", "%[b1]", "%[b2]", "%[b3]", "%[addr]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t",
+                   "s_mov_b32 m0, %[j]", L3C_CROSS_SELECT)
+        "s_waitcnt lgkmcnt(0)\n\t"
+        L3C_SYMBOL("%[b0]", "%[b1]", "%[b2]", "%[b3]",
+                   L3C_ROW_READS("%[a0]", "%[a1]", "%[a2_]", "%[a3]", "%[a2]") "v_add_u32 %[addr], %[rowb], %[addr]\n\t",
+                   "s_add_u32 m0, %[j], 1", "s_add_u32 %[j], %[j], 2\n\t")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
+        "s_mov_b32 %[value], s97\n\ts_mov_b64 %[buf], s[98:99]"
+        : [a0] "+v"(A.a), [a1] "+v"(A.b), [a2_] "+v"(A.c), [a3] "+v"(A.d), [b0] "+v"(B.a), [b1] "+v"(B.b), [b2] "+v"(B.c),
+          [b3] "+v"(B.d), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3), [sel] "=&v"(sel), [sel1] "=&v"(sel1),
+          L3C_BLOCK_STATE_OPERANDS
+        : [cur] "v"(window), [across] "v"(addr_cross), [rowb] "s"(row_bytes), [R] "s"(R), [top] "s"(top)
+        : "v96", "v97", "v98", "v99", "v100", L3C_BLOCK_CLOBBERS);
+    lean_block_uniform(st, wrel, minspan, value);
 }
 
 template <int NJ, bool ALLVALID, int IPB_ = (NJ == 1 ? 3 : 9)>
@@ -1172,7 +1224,7 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
         uint32_t x = 0;
         const bool full_block = k + 1u < n_blocks;   // a full block that does not hold the stream's last symbol
         bool done = false;
-        if constexpr (NJ == 4 && ALLVALID) {
+        if constexpr (NJ == 1 || ALLVALID) {
             // the hand-written loop, unless the bit window could run out inside the block (a symbol takes at most one word)
             if (full_block) {
                 // the bit window: a block takes at most R <= 32 words (one a symbol).  Window indices stay below 64 if the block
@@ -1186,7 +1238,7 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
                 }
                 const LeanState saved = st;
                 uint32_t minspan = 0xFFFFFFFFu;
-                lean_block_asm(rowA, rowB, st, wrel, minspan, window, kept, addr_next, addr_cross, row_bytes, R, top);
+                lean_block_asm(rowA, rowB, valid, st, wrel, minspan, window, kept, addr_next, addr_cross, row_bytes, R, top);
                 st.widx = src.base + wofs + wrel;
                 done = minspan != 0u && st.bad == 0u;
                 if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range or a bad value: again, the careful way

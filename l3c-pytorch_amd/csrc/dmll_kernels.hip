@@ -16,13 +16,15 @@
 //   cdf(l) = sum_k pi_k * sigmoid((t_l - mu'_k) * exp(-ls_k))   sequential k, mul then add   (torchac.py:181-200)
 //   entry  = uint16(rint(cdf * (65536 - (Lp-1))) + l)            round-half-even, wraps mod 2^16 (torchac.py:203-213)
 #include "ac_core.h"
+#include "dmll_core.h"
 #include "l3c_common.h"
 
 namespace {
 
 constexpr float kLogScalesMin = -7.0f;
 
-__device__ __forceinline__ float sigmoid_f(float a) { return 1.0f / (1.0f + expf(-a)); }
+using l3c::sigmoid_f;
+using l3c::sigmoid_sat;   // csrc/dmll_core.h
 
 // Accessor concept: float operator()(int ch) -- channel `ch` (0..Kp-1) of the current pixel.
 
@@ -73,19 +75,6 @@ __device__ __forceinline__ MixComponent mix_component_e(Get get, const MixStats 
         m.mu = m.mu + (a + b);
     }
     return m;
-}
-
-// sigmoid_f with its two saturated ends taken EXACTLY, without the expf and the division -- same bits as sigmoid_f:
-//   a >= 16.7:  expf(-a) <= 5.6e-8 < 2^-24, so 1.0f + expf(-a) rounds to 1.0f and the quotient is 1.0f;
-//   a <= -89:   expf(-a) overflows to +inf (e^89 > FLT_MAX), 1.0f + inf = inf, 1.0f / inf = 0.0f.
-// (Between -89 and -16.7 the value is tiny but not zero and has to be computed.)  A CDF row evaluates every mixture component
-// at all Lp targets; a component only has unsaturated terms within (-89 .. 16.7) sigma of its mean -- for the entries above
-// that band, usually most of the row, the ~25 instructions of expf + division are skipped (a divergent branch: a wavefront
-// takes the long path only if one of its lanes needs it).
-__device__ __forceinline__ float sigmoid_sat(float a) {
-    if (a >= 16.7f) return 1.0f;
-    if (a <= -89.0f) return 0.0f;
-    return 1.0f / (1.0f + expf(-a));
 }
 
 __device__ __forceinline__ float cdf_term(float pi, float mu, float inv_sigma, float target) {
@@ -181,7 +170,7 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
                                                                int rgb, int c, int64_t range0, int64_t range_len, int Lp,
-                                                               uint16_t *__restrict__ cdf) {
+                                                               uint16_t *__restrict__ cdf, int32_t *__restrict__ not_monotone) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kTablePix][Kp + 1]
     __shared__ float s_pi[kTablePix][kMaxK], s_mu[kTablePix][kMaxK], s_inv[kTablePix][kMaxK];
     __shared__ float s_max[kTablePix], s_den[kTablePix];
@@ -228,6 +217,13 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
     const int count = npix * Lp;
     uint16_t *out = cdf + (b * range_len + off) * Lp;
     const bool aligned4 = ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
+    // The strict-monotonicity check the decoder needs (l3c_cdf_check_monotone: entries 0 .. Lp-2 of every row) is done on the
+    // entries while they are in registers instead of re-reading the table (a 24 GB pass per batch of 128 otherwise): a thread
+    // holds entries e, e + 1; entry e + 2 is the next lane's first; what a wavefront's last lane needs comes from another
+    // wavefront or the next turn of this loop and goes through s_edge, checked after the loop.
+    __shared__ uint32_t s_edge[kTablePix * 260 / 128 + 2][2];   // per run of 128 entries: its first and its last entry
+    const int lane = tid & 63;
+    bool bad = false;
     for (int e = tid * 2; e < count; e += 512) {
         uint32_t v[2];
 #pragma unroll
@@ -245,6 +241,24 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
             out[e] = (uint16_t)v[0];
             if (e + 1 < count) out[e + 1] = (uint16_t)v[1];
         }
+        if (not_monotone) {   // pairs (m, m + 1) with m <= Lp - 3 inside a row: entry index mod Lp
+            const int l0 = e % Lp;
+            bad = bad || (e + 1 < count && l0 <= Lp - 3 && !(v[0] < v[1]));
+            const uint32_t next = (uint32_t)__shfl_down((int)v[0], 1, 64);   // entry e + 2 (lanes 0 .. 62)
+            const int l1 = l0 + 1 < Lp ? l0 + 1 : 0;
+            bad = bad || (lane < 63 && e + 2 < count && l1 <= Lp - 3 && !(v[1] < next));
+            if (lane == 0) s_edge[e >> 7][0] = v[0];
+            if (lane == 63) s_edge[e >> 7][1] = v[1];
+        }
+    }
+    if (not_monotone) {
+        __syncthreads();
+        const int runs = (count + 127) >> 7;   // run j: entries 128 j .. 128 j + 127; its last entry against the next run's first
+        for (int j = tid; j + 1 < runs; j += 256) {
+            const int m = (128 * j + 127) % Lp;
+            bad = bad || (m <= Lp - 3 && !(s_edge[j][1] < s_edge[j + 1][0]));
+        }
+        if (__any(bad) && lane == 0) atomicOr(not_monotone, 1);
     }
 }
 
@@ -477,10 +491,9 @@ int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets,
     L3C_REQUIRE(lds <= 48 * 1024, "Kp too large for the LDS tile");
     const dim3 grid((unsigned)((npix + kTablePix - 1) / kTablePix), (unsigned)B);
     hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, c,
-                       pix0, npix, Lp, cdf);
+                       pix0, npix, Lp, cdf, not_monotone);
     int rc = l3c::check_launch("cdf_table_from_P_kernel");
-    if (rc == L3C_OK && not_monotone) rc = l3c_cdf_check_monotone(cdf, B * npix, Lp, not_monotone, stream);
-    return rc;
+    return rc;   // (the kernel has checked the rows while it held them: not_monotone)
 }
 
 int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C,

@@ -190,3 +190,15 @@ def test_coding_targets_on_the_device_are_the_oracles_bits(x_min, x_max, L):
     assert got.cpu().numpy().tobytes() == want.numpy().tobytes()
     l = torch.zeros(1, 4, 2, 2, device='cuda')
     assert torch.equal(CodingCDFNonshared(l, 3 if L == 256 else 5, dmll).targets.cpu(), want)
+
+
+def test_the_kernels_sigmoid_is_the_plain_one_on_every_float():
+    """csrc/dmll_core.h: sigmoid_sat (saturated ends taken as constants, the middle without the library's range clamps, division
+    scaling and fix-up) must return the bits of 1 / (1 + expf(-a)) for EVERY float -- the tables of rounds 1-3, the fixtures
+    and the files written with them stay what they are.  All 2^32 bit patterns, on the device."""
+    from l3c_pytorch_amd import _lib, ops
+    bad = torch.zeros(1, dtype=torch.int64, device='cuda')
+    first = torch.full((1,), -1, dtype=torch.int32, device='cuda')      # 0xFFFFFFFF
+    _lib.call_xcheck('l3c_xcheck_sigmoid_exhaustive', ops.ptr(bad), ops.ptr(first), ops.stream())
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, 'first differing input bits: 0x{:08x}'.format(int(first.item()) & 0xFFFFFFFF)

@@ -4,7 +4,7 @@
     rocprofv3 --kernel-trace -d gpurun_out/dtrace -o run --output-format csv -- python tools/decode_profile.py 128
     python tools/decode_overlap.py gpurun_out/dtrace
 
-Intervals of cdf_table_from_P_kernel (T) and ac_decode_ring_kernel (D) launches: union length of each, length of their
+Intervals of cdf_table_from_P_kernel (T) and ac_decode_lean_kernel / ac_decode_ring_kernel (D) launches: union length of each, length of their
 intersection, and the average launch durations -- `T + D - both` is the wall time the pipelined chunk steps need."""
 import csv
 import glob
