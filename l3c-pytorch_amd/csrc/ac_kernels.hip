@@ -89,8 +89,7 @@ __device__ __forceinline__ uint32_t pair_step(uint32_t &u, uint32_t &range, uint
     const uint32_t us = u1 << 1;
     const uint32_t zz = us & pair_partner(us);            // (low' & ~high') << 1
     const uint32_t h = ~((u1 ^ o1) | zz);
-    int t;
-    asm("v_ffbh_u32 %0, %1" : "=v"(t) : "v"(h));         // == role_shift(u1, o1); h != 0 for low' < high'
+    const int t = __builtin_clz(h);                       // == role_shift(u1, o1); h != 0 for low' < high' (v_ffbh_u32: no v_min on top)
     range = ~(sum << t);                                  // == role_range of the renormalised pair
     u = (u1 << t) & 0x7FFFFFFFu;                          // == role_renorm(u1, t)
     asm volatile("" : "+v"(range));   // keep `range` a value of its own: its two halves then feed the 24-bit multiplies as SDWA selects

@@ -48,7 +48,7 @@ def main():
         for r in csv.DictReader(open(f)):
             a, b = int(r['Start_Timestamp']), int(r['End_Timestamp'])
             n = r['Kernel_Name']
-            (T if 'cdf_table_from_P_kernel' in n else D if 'ac_decode_ring_kernel' in n else other).append((a, b))
+            (T if 'cdf_table_from_P_kernel' in n else D if ('ac_decode_ring_kernel' in n or 'ac_decode_lean_kernel' in n) else other).append((a, b))
     if not T or not D:
         print('no table / decoder launches found under', root)
         return

@@ -31,12 +31,12 @@ import sys
 
 KEYS = [('conv_wino4_kernel', 'conv_wino4_kernel'), ('conv_wino4x_kernel', 'conv_wino4_kernel'), ('conv_wino_kernel', 'conv_wino_kernel'),
         ('cdf_table_from_P_kernel', 'cdf_table_from_P_kernel'),
-        ('ac_decode_ring_kernel', 'ac_decode_ring_kernel'), ('channel_params_kernel', 'channel_params_kernel'), ('conv_pw_kernel', 'conv k1 s1 (mfma)'), ('conv_lds_kernel<1', 'conv k1 s1 (mfma)'), ('conv_mfma_kernel<1', 'conv k1 s1 (mfma)'),
+        ('ac_decode_lean_kernel', 'ac_decode_lean_kernel'), ('ac_decode_ring_kernel', 'ac_decode_ring_kernel'), ('channel_params_kernel', 'channel_params_kernel'), ('conv_pw_kernel', 'conv k1 s1 (mfma)'), ('conv_lds_kernel<1', 'conv k1 s1 (mfma)'), ('conv_mfma_kernel<1', 'conv k1 s1 (mfma)'),
         ('conv_mfma_kernel<5', 'conv k5 s2 (mfma)'), ('encode_intervals_kernel', 'encode_intervals_kernel'),
         ('rgb_head_kernel', 'rgb_head_kernel'), ('ac_state_groups_kernel', 'ac_state_groups_kernel'),
         ('ac_pack_groups_kernel', 'ac_pack_groups_kernel'), ('to_q_quantize_kernel', 'to_q_quantize_kernel'),
         ('dec_head_kernel', 'dec_head_kernel')]
-DECODE_KEYS = ('cdf_table_from_P_kernel', 'ac_decode_ring_kernel', 'channel_params_kernel', 'ac_decode_fused_kernel')
+DECODE_KEYS = ('cdf_table_from_P_kernel', 'ac_decode_lean_kernel', 'ac_decode_ring_kernel', 'channel_params_kernel')
 
 
 def key_of(name):
