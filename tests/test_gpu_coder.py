@@ -32,9 +32,12 @@ def test_decode_truncated_stream_like_reference(golden):
     assert (dec == g['truncated/decoded']).all()
 
 
-@pytest.mark.parametrize('S,N,Lp', [(1, 1, 257), (3, 65, 26), (70, 1000, 257), (130, 517, 26), (64, 64, 3), (5, 4097, 257)])
+@pytest.mark.parametrize('S,N,Lp', [(1, 1, 257), (3, 65, 26), (70, 1000, 257), (130, 517, 26), (64, 64, 3), (5, 4097, 257),
+                                    (9, 700, 130), (4, 900, 65), (3, 1300, 200), (2, 50, 2), (50, 600, 256)])
 def test_many_streams_vs_oracle(S, N, Lp):
-    """streams per lane (encode) / per wavefront (decode); S crosses the 64-lane boundary, N the 64-symbol blocks."""
+    """streams per lane pair (encode) / per wavefront (decode); S crosses the wavefront boundaries, N the 64-symbol blocks; alphabets
+    of one row register (Lp <= 65: every lane a table entry at 65), of four with spare lanes (130, 200, 256: the compiled symbol of
+    the lean decoder) and the full 257 (its hand-written loop); 50 streams: the small ring."""
     from tests import gpu_util as gu
     rng = np.random.RandomState(S * 1000 + N)
     tabs = gu.random_tables(rng, S, N, Lp, shape=rng.choice([0.05, 0.3, 2.0]))
