@@ -14,7 +14,6 @@
 //                                 to be monotone): the reference's literal binary search over v_readlane
 //   ac_decode_const_row_kernel    the same for one row shared by all symbols (the uniform prior of the coarsest scale)
 //   check_monotone_kernel         flags tables that are not strictly increasing (selects the decode path)
-#include <mutex>
 #include <vector>
 
 #include "ac_core.h"
@@ -97,37 +96,27 @@ __device__ __forceinline__ uint32_t pair_step(uint32_t &u, uint32_t &range, uint
     return u1;
 }
 
-// A launch covers the blocks [n_chunks * part / n_parts, n_chunks * (part + 1) / n_parts) of every stream; between the parts the
-// pair's state waits in `carry` (kCarryWords words per stream: u of role 0, u of role 1, range; then phase 2's four).
-constexpr int kCarryWords = 8;
 __device__ __forceinline__ void ac_state_body(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
-                                              uint32_t *__restrict__ final_low, uint32_t *__restrict__ carry, int64_t block,
-                                              int part, int n_parts) {
+                                              uint32_t *__restrict__ final_low, int64_t block) {
     int64_t s = block * 32 + (threadIdx.x >> 1);
     const int role = threadIdx.x & 1;
     const bool active = s < n_streams;
     if (!active) s = n_streams - 1;   // keep the wavefront converged; duplicates rewrite identical values
-    // low = 0, high = 0xFFFFFFFF, or where the previous part stopped.  (The loads are UNCONDITIONAL -- for the first part from a
-    // word that exists and is not used: behind a conditional load the compiler awaits everything in the loop with vmcnt(0).)
-    const gu32 *cu = (const gu32 *)(part > 0 ? carry + s * kCarryWords + role : final_low + s);
-    const gu32 *cr = (const gu32 *)(part > 0 ? carry + s * kCarryWords + 2 : final_low + s);
-    const uint32_t u_in = *cu, range_in = *cr;
-    uint32_t u = part > 0 ? u_in : 0u, range = part > 0 ? range_in : 0xFFFFFFFFu;
+    uint32_t u = 0, range = 0xFFFFFFFFu;   // low = 0, high = 0xFFFFFFFF
     const uint32_t round = l3c::role_round(role);
     __builtin_amdgcn_s_setprio(3);    // a few long-lived latency-bound waves next to MFMA-heavy kernels: issue first
 
     // One 64-symbol block (16 x dwordx4 per lane) is processed while the next one is already in flight: ~2 us of serial
     // work per block hides the HBM latency even when the conv kernels of the next batch saturate the memory system.
-    const int64_t n_all = (n_sym + kChunk - 1) / kChunk;
-    const int64_t c_first = n_all * part / n_parts, n_chunks = n_all * (part + 1) / n_parts;   // this launch: [c_first, n_chunks)
+    const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
     auto chunk_ptr = [&](int64_t c) { return (gu32x4 *)(iv + iv_index(c, n_streams, s, role, 0)); };
     u32x4 cur[16], nxt[16];
-    {   // (unconditional, like the prefetch below: an empty part fetches a block it does not use)
-        const gu32x4 *p = chunk_ptr(c_first < n_all ? c_first : n_all - 1);
+    {
+        const gu32x4 *p = chunk_ptr(0);
 #pragma unroll
         for (int k = 0; k < 16; ++k) cur[k] = p[k];
     }
-    for (int64_t c = c_first; c < n_chunks; ++c) {
+    for (int64_t c = 0; c < n_chunks; ++c) {
         {   // UNCONDITIONAL (the last block is fetched again and dropped): with a skipped prefetch as a second path into the
             // code below the compiler has to await `cur` with vmcnt(0) -- i.e. the loads just issued
             const gu32x4 *p = chunk_ptr(c + 1 < n_chunks ? c + 1 : c);
@@ -157,11 +146,7 @@ __device__ __forceinline__ void ac_state_body(uint32_t *__restrict__ iv, int64_t
 #pragma unroll
         for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
     }
-    if (active && part + 1 < n_parts) {
-        carry[s * kCarryWords + role] = u;
-        if (role == 0) carry[s * kCarryWords + 2] = range;
-    }
-    if (active && role == 0 && part + 1 == n_parts) final_low[s] = u;
+    if (active && role == 0) final_low[s] = u;
 }
 
 // One group of equally long streams for the grouped launches (mirrors l3c_ac_group of include/l3c_hip.h).
@@ -170,7 +155,6 @@ struct AcGroup {
     uint8_t *out;
     uint32_t *out_nbytes;
     uint32_t *final_low;
-    uint32_t *carry;           // kCarryWords words per stream (launches in parts)
     int64_t n_streams, n_sym, out_stride;
 };
 
@@ -185,11 +169,11 @@ __global__ __launch_bounds__(64) void ac_groups_upload_kernel(AcGroupPack pack, 
 
 __global__ __launch_bounds__(64) void ac_state_kernel(uint32_t *__restrict__ iv, int64_t n_streams, int64_t n_sym,
                                                       uint32_t *__restrict__ final_low) {
-    ac_state_body(iv, n_streams, n_sym, final_low, nullptr, blockIdx.x, 0, 1);
+    ac_state_body(iv, n_streams, n_sym, final_low, blockIdx.x);
 }
 
 // Grouped launch: block -> (group, 32-stream block inside the group) by walking the (short) descriptor array.
-__global__ __launch_bounds__(64) void ac_state_groups_kernel(const AcGroup *__restrict__ groups, int n_groups, int part, int n_parts) {
+__global__ __launch_bounds__(64) void ac_state_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
     int64_t blk = blockIdx.x;
     int g = 0;
     for (; g < n_groups; ++g) {
@@ -199,7 +183,7 @@ __global__ __launch_bounds__(64) void ac_state_groups_kernel(const AcGroup *__re
     }
     if (g >= n_groups) return;
     const AcGroup gr = groups[g];
-    ac_state_body(gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, gr.carry, blk, part, n_parts);
+    ac_state_body(gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, blk);
 }
 
 // ---- encoder, phase 2: records -> bits, one stream per wavefront, 64 symbols per step ------------------------------------
@@ -248,8 +232,7 @@ __device__ __forceinline__ uint32_t wave_prev_lane(uint32_t v) { return dpp0<0x1
 __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__restrict__ rec, int64_t n_streams,
                                              int64_t n_sym, const uint32_t *__restrict__ final_low,
                                              uint8_t *__restrict__ out, int64_t out_stride,
-                                             uint32_t *__restrict__ out_nbytes, int64_t s, uint32_t *__restrict__ carry,
-                                             int part, int n_parts) {
+                                             uint32_t *__restrict__ out_nbytes, int64_t s) {
     const int lane = threadIdx.x;
     uint32_t *words = reinterpret_cast<uint32_t *>(out + s * out_stride);
     gu32 *gwords = (gu32 *)words;              // see the note at gu32: exact vmcnt counts for the ring of records below
@@ -257,30 +240,22 @@ __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__re
     uint32_t pending = 0;          // wave-uniform
     uint64_t bit_off = 0;          // bits emitted so far (wave-uniform)
     uint32_t carry_word = 0;       // the incomplete output word, MSB aligned
-    if (part > 0) {                // where the previous part of this stream stopped
-        const uint32_t *cw = carry + s * kCarryWords + 3;
-        pending = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[0]);
-        bit_off = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)cw[1]) |
-                  ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)cw[2]) << 32);
-        carry_word = (uint32_t)__builtin_amdgcn_readfirstlane((int)cw[3]);
-    }
 
-    const int64_t n_all = (n_sym + kChunk - 1) / kChunk;
-    const int64_t c_first = n_all * part / n_parts, n_chunks = n_all * (part + 1) / n_parts;   // this launch: [c_first, n_chunks)
+    const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
     constexpr int PF = 8;          // records in flight: 8 steps of 64 symbols
     uint32_t ring[PF], ring_hi[PF];   // what phase 1 left of a symbol: low' and ~high' (csrc/ac_core.h: record_from_pair)
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        ring[d] = c_first + d < n_chunks ? grec[iv_index(c_first + d, n_streams, s, 0, lane)] : 0u;
-        ring_hi[d] = c_first + d < n_chunks ? grec[iv_index(c_first + d, n_streams, s, 1, lane)] : 0u;
+        ring[d] = d < n_chunks ? grec[iv_index(d, n_streams, s, 0, lane)] : 0u;
+        ring_hi[d] = d < n_chunks ? grec[iv_index(d, n_streams, s, 1, lane)] : 0u;
     }
-    for (int64_t c0 = c_first; c0 < n_chunks; c0 += PF)
+    for (int64_t c0 = 0; c0 < n_chunks; c0 += PF)
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
         const int64_t c = c0 + d;
         if (c >= n_chunks) break;   // wave-uniform
         const uint32_t r = (c * kChunk + lane < n_sym) ? l3c::record_from_pair(ring[d], ring_hi[d]) : 0u;   // a zero record emits nothing
-        {   // unconditional, clamped (see ac_state_body) -- to THIS part's blocks: the next part's are still being written
+        {   // unconditional, clamped: see ac_state_body
             const int64_t cn = c + PF < n_chunks ? c + PF : n_chunks - 1;
             ring[d] = grec[iv_index(cn, n_streams, s, 0, lane)];
             ring_hi[d] = grec[iv_index(cn, n_streams, s, 1, lane)];
@@ -349,16 +324,6 @@ __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__re
         bit_off += total;
         pending = new_pending;
     }
-    if (part + 1 < n_parts) {      // not the end of the stream: leave the state for the next part
-        if (lane == 0) {
-            uint32_t *cw = carry + s * kCarryWords + 3;
-            cw[0] = pending;
-            cw[1] = (uint32_t)bit_off;
-            cw[2] = (uint32_t)(bit_off >> 32);
-            cw[3] = carry_word;
-        }
-        return;
-    }
     // flush (torchac.cpp:209-219): pending + 1 complements after the quadrant bit, zero padding to a byte
     {
         const uint32_t nb = (uint32_t)(bit_off & 31u);
@@ -377,10 +342,10 @@ __global__ __launch_bounds__(64) void ac_pack_kernel(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ final_low, uint8_t *__restrict__ out,
                                                      int64_t out_stride, uint32_t *__restrict__ out_nbytes) {
     __shared__ uint32_t buf[80];   // the bits of one 64-symbol step: <= 31 carried + 64 * 32 new = 2079 bits = 65 words
-    ac_pack_body(buf, rec, n_streams, n_sym, final_low, out, out_stride, out_nbytes, blockIdx.x, nullptr, 0, 1);
+    ac_pack_body(buf, rec, n_streams, n_sym, final_low, out, out_stride, out_nbytes, blockIdx.x);
 }
 
-__global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__restrict__ groups, int n_groups, int part, int n_parts) {
+__global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
     __shared__ uint32_t buf[80];
     int64_t blk = blockIdx.x;
     int g = 0;
@@ -390,7 +355,7 @@ __global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__res
     }
     if (g >= n_groups) return;
     const AcGroup gr = groups[g];
-    ac_pack_body(buf, gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, gr.out, gr.out_stride, gr.out_nbytes, blk, gr.carry, part, n_parts);
+    ac_pack_body(buf, gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, gr.out, gr.out_stride, gr.out_nbytes, blk);
 }
 
 // ---- decoder -------------------------------------------------------------------------------------------------------
@@ -1373,30 +1338,6 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
     return l3c::check_launch("ac_decode_ring_kernel<generic>");
 }
 
-// One side stream per device for l3c_ac_encode_groups' launches in parts (created on first use, never destroyed).
-hipStream_t encode_side_stream() {
-    static std::mutex mu;
-    static hipStream_t streams[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!streams[dev]) {
-        // a stream of another PRIORITY sits in a hardware queue of its own: two streams of equal priority may share one of the
-        // runtime's few queues (round robin), and then the parts below would simply run one after the other
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = greatest = 0;
-        if (hipStreamCreateWithPriority(&streams[dev], hipStreamNonBlocking, greatest) != hipSuccess) streams[dev] = nullptr;
-    }
-    return streams[dev];
-}
-
-#define L3C_HIP_OK(call, rc)                                                        \
-    do {                                                                            \
-        if ((rc) == L3C_OK) {                                                       \
-            (rc) = l3c::check_hip((call), #call);                                   \
-        }                                                                           \
-    } while (0)
-
 }  // namespace
 
 extern "C" {
@@ -1444,9 +1385,7 @@ int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t
 }
 
 int64_t l3c_ac_encode_groups_workspace_bytes(int n_groups, int64_t total_streams) {
-    // descriptors | final low per stream | the state carried between the parts of a launch in parts (kCarryWords words per stream)
-    return (((int64_t)n_groups * (int64_t)sizeof(AcGroup) + 255) / 256) * 256 + ((total_streams * 4 + 255) / 256) * 256 +
-           total_streams * kCarryWords * 4;
+    return (((int64_t)n_groups * (int64_t)sizeof(AcGroup) + 255) / 256) * 256 + ((total_streams * 4 + 255) / 256) * 256;
 }
 
 int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *workspace, l3c_stream_t stream) {
@@ -1456,12 +1395,6 @@ int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *wo
     int64_t state_blocks = 0, pack_blocks = 0, streams = 0;
     const size_t desc_bytes = (((size_t)n_groups * sizeof(AcGroup) + 255) / 256) * 256;
     uint32_t *final_low = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + desc_bytes);
-    int64_t total_streams = 0, longest = 0;
-    for (int g = 0; g < n_groups; ++g) {
-        total_streams += groups_host[g].n_streams;
-        longest = groups_host[g].n_sym > longest ? groups_host[g].n_sym : longest;
-    }
-    uint32_t *carry = final_low + ((total_streams * 4 + 255) / 256) * 64;
     for (int g = 0; g < n_groups; ++g) {
         const l3c_ac_group &in = groups_host[g];
         L3C_REQUIRE(in.intervals && in.out && in.out_nbytes, "null pointer in group");
@@ -1469,8 +1402,7 @@ int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *wo
         L3C_REQUIRE(in.out_stride_bytes % 4 == 0 && in.out_stride_bytes >= l3c_ac_max_bytes(in.n_sym), "output stride too small");
         L3C_REQUIRE((reinterpret_cast<uintptr_t>(in.out) & 3) == 0 && (reinterpret_cast<uintptr_t>(in.intervals) & 15) == 0,
                     "misaligned buffer in group");
-        host[g] = AcGroup{in.intervals, in.out, in.out_nbytes, final_low + streams, carry + streams * kCarryWords, in.n_streams, in.n_sym,
-                          in.out_stride_bytes};
+        host[g] = AcGroup{in.intervals, in.out, in.out_nbytes, final_low + streams, in.n_streams, in.n_sym, in.out_stride_bytes};
         state_blocks += (in.n_streams + 31) / 32;
         pack_blocks += in.n_streams;
         streams += in.n_streams;
@@ -1488,45 +1420,11 @@ int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *wo
         rc = l3c::check_launch("ac_groups_upload_kernel");
         if (rc != L3C_OK) return rc;
     }
-    hipStream_t st = l3c::as_stream(stream);
-    // A few long streams (one image, a few images): both phases are serial per stream and phase 2 (3.4 ms per 393 216 symbols)
-    // would start when phase 1 (13.5 ms) ends.  In kParts parts instead -- phase 2 of part p on a side stream while phase 1 runs
-    // part p + 1; the state of either phase waits in the workspace between its parts; `stream` continues when the side stream
-    // is through.  Large batches keep the two plain launches: their phase 2 has streams enough to fill the machine.
-    constexpr int kParts = 4;
-    hipStream_t side = nullptr;
-    if (longest >= 32768 && total_streams <= 256) side = encode_side_stream();
-    if (!side) {
-        hipLaunchKernelGGL(ac_state_groups_kernel, dim3((unsigned)state_blocks), dim3(64), 0, st, dev, n_groups, 0, 1);
-        rc = l3c::check_launch("ac_state_groups_kernel");
-        if (rc != L3C_OK) return rc;
-        hipLaunchKernelGGL(ac_pack_groups_kernel, dim3((unsigned)pack_blocks), dim3(64), 0, st, dev, n_groups, 0, 1);
-        return l3c::check_launch("ac_pack_groups_kernel");
-    }
-    hipEvent_t ev = nullptr;
-    rc = L3C_OK;
-    for (int part = 0; part < kParts && rc == L3C_OK; ++part) {
-        hipLaunchKernelGGL(ac_state_groups_kernel, dim3((unsigned)state_blocks), dim3(64), 0, st, dev, n_groups, part, kParts);
-        rc = l3c::check_launch("ac_state_groups_kernel");
-        if (rc != L3C_OK) break;
-        L3C_HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), rc);
-        if (rc != L3C_OK) break;
-        L3C_HIP_OK(hipEventRecord(ev, st), rc);
-        L3C_HIP_OK(hipStreamWaitEvent(side, ev, 0), rc);
-        L3C_HIP_OK(hipEventDestroy(ev), rc);       // (released when the recorded work is done)
-        if (rc != L3C_OK) break;
-        hipLaunchKernelGGL(ac_pack_groups_kernel, dim3((unsigned)pack_blocks), dim3(64), 0, side, dev, n_groups, part, kParts);
-        rc = l3c::check_launch("ac_pack_groups_kernel");
-    }
-    // `stream` waits for the side stream whatever happened above (nothing of this call may be in flight behind its back)
-    int rc2 = L3C_OK;
-    L3C_HIP_OK(hipEventCreateWithFlags(&ev, hipEventDisableTiming), rc2);
-    if (rc2 == L3C_OK) {
-        L3C_HIP_OK(hipEventRecord(ev, side), rc2);
-        L3C_HIP_OK(hipStreamWaitEvent(st, ev, 0), rc2);
-        L3C_HIP_OK(hipEventDestroy(ev), rc2);
-    }
-    return rc != L3C_OK ? rc : rc2;
+    hipLaunchKernelGGL(ac_state_groups_kernel, dim3((unsigned)state_blocks), dim3(64), 0, l3c::as_stream(stream), dev, n_groups);
+    rc = l3c::check_launch("ac_state_groups_kernel");
+    if (rc != L3C_OK) return rc;
+    hipLaunchKernelGGL(ac_pack_groups_kernel, dim3((unsigned)pack_blocks), dim3(64), 0, l3c::as_stream(stream), dev, n_groups);
+    return l3c::check_launch("ac_pack_groups_kernel");
 }
 
 int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t *in, const int64_t *in_offsets,
