@@ -136,4 +136,55 @@ void hostsim_decode(const uint16_t *cdf, long long row_stride, int Lp, const uin
         l3c::decode_advance(low, high, value, c_lo, c_hi, src);
     }
 }
+// Random single steps from every kind of renormalised state: the lane-pair form (role_term / role_shift / role_renorm / role_range) and
+// the decoder's lean_advance against interval_update + renorm_counts.  Returns the number of differing results (0 expected).
+long long hostsim_step_forms_agree(long long n, unsigned long long seed) {
+    unsigned long long x = seed * 0x9E3779B97F4A7C15ull + 1;
+    auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return (uint32_t)(x >> 16); };
+    long long bad = 0;
+    for (long long i = 0; i < n; ++i) {
+        // a state the coder can be in: the full range, or low = 0..., high = 1... and not both in the underflow position
+        uint32_t low, high;
+        const uint32_t kind = rnd() % 8;
+        if (kind == 0) { low = 0; high = 0xFFFFFFFFu; }
+        else {
+            low = rnd() & 0x7FFFFFFFu;
+            high = rnd() | 0x80000000u;
+            if (kind == 1) { low = 0x3FFFFFFFu; high = 0xC0000000u; }                    // just outside the underflow position
+            if (kind == 2) { low &= 0x3FFFFFFFu; }                                        // low in the lowest quarter
+            if ((low & 0x40000000u) && !(high & 0x40000000u)) high |= 0x40000000u;         // (the E3 position is never a resting state)
+        }
+        uint32_t c_lo = rnd() % 65536u, c_hi = rnd() % 65537u;
+        if (kind == 3) { c_lo = 0; c_hi = 0x10000u; }
+        if (kind == 4) { c_hi = c_lo + 1u; }                                              // width-1 interval
+        if (kind == 5) { c_hi = 0x10000u; }
+        if (c_hi <= c_lo) { const uint32_t t = c_lo; c_lo = c_hi; c_hi = t + 1u; }
+        if (c_hi > 0x10000u) c_hi = 0x10000u;
+        if (c_lo >= c_hi) c_lo = c_hi - 1u;
+        // reference form
+        uint32_t l1 = low, h1 = high;
+        l3c::interval_update(l1, h1, c_lo, c_hi);
+        int n1, m1;
+        uint32_t lf, hf;
+        l3c::renorm_counts(l1, h1, n1, m1, lf, hf);
+        // lane pair
+        const uint32_t range = high - low;
+        uint32_t u1[2] = {low + l3c::role_term(range, l3c::role_word(c_lo, c_hi, 0), l3c::role_round(0)),
+                          ~high + l3c::role_term(range, l3c::role_word(c_lo, c_hi, 1), l3c::role_round(1))};
+        const int t = l3c::role_shift(u1[0], u1[1]);
+        const uint32_t u0f = l3c::role_renorm(u1[0], t), u1f = l3c::role_renorm(u1[1], t);
+        bool ok = u1[0] == l1 && u1[1] == ~h1 && t == n1 + m1 && u0f == lf && u1f == ~hf && l3c::role_range(u0f, u1f) == hf - lf;
+        ok = ok && l3c::role_shift(u1[1], u1[0]) == t;
+        const uint32_t rec = l3c::record_from_pair(u1[0], u1[1]);
+        ok = ok && l3c::record_n(rec) == (uint32_t)n1 && l3c::record_m(rec) == (uint32_t)m1;
+        // decoder form
+        uint32_t dl = low, dnh = ~high, dr = range, msb;
+        const uint32_t t_lo = (uint32_t)(((uint64_t)range * c_lo + c_lo) >> 16), t_hi = (uint32_t)(((uint64_t)range * c_hi + c_hi) >> 16);
+        const int c = l3c::lean_advance(dl, dnh, dr, t_lo, t_hi, c_hi == 0x10000u, msb);
+        ok = ok && c == n1 + m1 && dl == lf && dnh == ~hf && dr == hf - lf && msb == (m1 ? 0x80000000u : 0u);
+        bad += ok ? 0 : 1;
+    }
+    return bad;
 }
+}
+

@@ -27,6 +27,8 @@ def _get():
         lib.hostsim_decode.restype = None
         lib.hostsim_decode.argtypes = [ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p,
                                        ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p, ctypes.c_longlong]
+        lib.hostsim_step_forms_agree.restype = ctypes.c_longlong
+        lib.hostsim_step_forms_agree.argtypes = [ctypes.c_longlong, ctypes.c_ulonglong]
         _lib = lib
     return _lib
 
@@ -48,3 +50,7 @@ def decode(tab, data, N, monotone):
     _get().hostsim_decode(tab.ctypes.data, tab.shape[1], tab.shape[1], buf.ctypes.data if len(buf) else None,
                           len(buf), int(monotone), out.ctypes.data, N)
     return out
+
+
+def step_forms_disagreements(n, seed):
+    return int(_get().hostsim_step_forms_agree(n, seed))

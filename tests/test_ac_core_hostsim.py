@@ -102,3 +102,11 @@ def test_hostsim_dyadic_table_meets_the_full_range_again():
     ref = ac.encode(tab, sym)
     assert hs.encode(tab, sym, fast=2) == ref and hs.encode(tab, sym, fast=True) == ref
     assert (hs.decode(tab, ref, N, 3) == sym).all() and (hs.decode(tab, ref, N, 2) == sym).all()
+
+
+def test_hostsim_single_steps_of_the_three_forms_agree():
+    """interval_update + renorm_counts (the reference's state machine in closed form), the encoder's lane-pair form and the decoder's
+    (low, ~high, range) form on five million random steps from every kind of resting state: full range, just outside the underflow
+    position, width-1 intervals, the top symbol -- the same bounds, the same n + m, the same record, the same underflow flip."""
+    for seed in range(5):
+        assert hs.step_forms_disagreements(1000000, seed) == 0, seed
