@@ -229,103 +229,158 @@ __device__ __forceinline__ uint32_t wave_segmented_sum(uint32_t val, uint32_t &f
 
 __device__ __forceinline__ uint32_t wave_prev_lane(uint32_t v) { return dpp0<0x138>(v); }   // wave_shr:1; lane 0 reads 0
 
-__device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__restrict__ rec, int64_t n_streams,
+// Shared memory of a pack block: the bit window of one step (<= 31 carried bits + kPackWaves * 64 symbols of <= 32 bits) and what the
+// wavefronts tell each other.
+constexpr int kPackWaves = 4;                          // wavefronts per stream: a step takes 4 x 64 symbols (round 4; one before)
+constexpr int kPackThreads = kPackWaves * 64;
+struct PackShared {
+    uint32_t buf[kPackWaves * 64 + 16];                // the window, in words
+    uint32_t rec[kPackThreads];                        // the step's records (for the serial path of long pending runs)
+    uint32_t flag[kPackWaves], val[kPackWaves];        // per wavefront: does it hold an emitter; its pending run with no carry-in
+    uint32_t bits[kPackWaves];                         // per wavefront: bits it emits
+    uint32_t rare;                                     // some symbol of the step emits more than 32 bits
+    uint32_t state[4];                                 // after the serial path: pending, bit_off (2 words), carry_word
+};
+
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// One stream per BLOCK of kPackWaves wavefronts; a step codes kPackWaves consecutive 64-symbol blocks, wavefront w the w-th of
+// them.  Inside a wavefront as before (segmented scan of the pending runs, prefix sum of the bits); between the wavefronts the
+// pending run and the bit offset are carried by a serial composition of four summaries: a wavefront with an emitter ends with
+// its own run (val), one without passes carry-in + its sum on.
+__device__ __forceinline__ void ac_pack_body(PackShared &sh, const uint32_t *__restrict__ rec, int64_t n_streams,
                                              int64_t n_sym, const uint32_t *__restrict__ final_low,
                                              uint8_t *__restrict__ out, int64_t out_stride,
                                              uint32_t *__restrict__ out_nbytes, int64_t s) {
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *words = reinterpret_cast<uint32_t *>(out + s * out_stride);
     gu32 *gwords = (gu32 *)words;              // see the note at gu32: exact vmcnt counts for the ring of records below
     const gu32 *grec = (const gu32 *)rec;
-    uint32_t pending = 0;          // wave-uniform
-    uint64_t bit_off = 0;          // bits emitted so far (wave-uniform)
-    uint32_t carry_word = 0;       // the incomplete output word, MSB aligned
+    uint32_t pending = 0;          // block-uniform
+    uint64_t bit_off = 0;          // bits emitted so far (block-uniform)
+    uint32_t carry_word = 0;       // the incomplete output word, MSB aligned (block-uniform)
 
     const int64_t n_chunks = (n_sym + kChunk - 1) / kChunk;
-    constexpr int PF = 8;          // records in flight: 8 steps of 64 symbols
+    const int64_t n_steps = (n_chunks + kPackWaves - 1) / kPackWaves;
+    constexpr int PF = 4;          // records in flight: 4 steps
     uint32_t ring[PF], ring_hi[PF];   // what phase 1 left of a symbol: low' and ~high' (csrc/ac_core.h: record_from_pair)
+    auto chunk_of = [&](int64_t step) {   // this wavefront's block of the step, clamped to the stream (a clamped block is not used)
+        const int64_t c = step * kPackWaves + wave;
+        return c < n_chunks ? c : n_chunks - 1;
+    };
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        ring[d] = d < n_chunks ? grec[iv_index(d, n_streams, s, 0, lane)] : 0u;
-        ring_hi[d] = d < n_chunks ? grec[iv_index(d, n_streams, s, 1, lane)] : 0u;
+        ring[d] = grec[iv_index(chunk_of(d), n_streams, s, 0, lane)];
+        ring_hi[d] = grec[iv_index(chunk_of(d), n_streams, s, 1, lane)];
     }
-    for (int64_t c0 = 0; c0 < n_chunks; c0 += PF)
+    for (int64_t t0 = 0; t0 < n_steps; t0 += PF)
 #pragma unroll
     for (int d = 0; d < PF; ++d) {
-        const int64_t c = c0 + d;
-        if (c >= n_chunks) break;   // wave-uniform
-        const uint32_t r = (c * kChunk + lane < n_sym) ? l3c::record_from_pair(ring[d], ring_hi[d]) : 0u;   // a zero record emits nothing
+        const int64_t step = t0 + d;
+        if (step >= n_steps) break;   // block-uniform
+        const int64_t c = step * kPackWaves + wave;
+        const uint32_t r = (c < n_chunks && c * kChunk + lane < n_sym) ? l3c::record_from_pair(ring[d], ring_hi[d]) : 0u;   // a zero record emits nothing
         {   // unconditional, clamped: see ac_state_body
-            const int64_t cn = c + PF < n_chunks ? c + PF : n_chunks - 1;
-            ring[d] = grec[iv_index(cn, n_streams, s, 0, lane)];
-            ring_hi[d] = grec[iv_index(cn, n_streams, s, 1, lane)];
+            ring[d] = grec[iv_index(chunk_of(step + PF), n_streams, s, 0, lane)];
+            ring_hi[d] = grec[iv_index(chunk_of(step + PF), n_streams, s, 1, lane)];
         }
         const uint32_t n = l3c::record_n(r), m = l3c::record_m(r), top = l3c::record_top(r);
         const bool emits = n != 0;
         // segmented inclusive scan: S_j = emits_j ? m_j : S_{j-1} + m_j  (a run of pending bits restarts at every emitter)
         uint32_t flag = emits ? 1u : 0u;
         uint32_t val = wave_segmented_sum(m, flag);
-        if (!flag) val += pending;                     // no emitter at or before this lane: the carried run continues
+        sh.rec[tid] = r;
+        if (lane == 63) {
+            sh.flag[wave] = flag;
+            sh.val[wave] = val;
+        }
+        if (tid == 0) sh.rare = 0u;
+        sh.buf[tid] = 0u;                              // (the window; word 0 gets the carried bits below)
+        if (tid < 16) sh.buf[kPackThreads + tid] = 0u;
+        __syncthreads();
+        // the pending run this wavefront starts with, and the one the step ends with
+        uint32_t pend_in = pending, pend_out = pending;
+#pragma unroll
+        for (int u = 0; u < kPackWaves; ++u) {
+            const uint32_t f = uni(sh.flag[u]), v_u = uni(sh.val[u]);
+            pend_out = f ? v_u : pend_out + v_u;
+            if (u + 1 == wave) pend_in = pend_out;
+        }
+        if (!flag) val += pend_in;                     // no emitter at or before this lane: the carried run continues
         // pending BEFORE symbol j = S_{j-1} (exclusive), S_{-1} = carried pending
         uint32_t p_before = wave_prev_lane(val);
-        if (lane == 0) p_before = pending;
+        if (lane == 0) p_before = pend_in;
         const uint32_t e = emits ? n + p_before : 0u;  // bits this symbol emits
-        const uint32_t new_pending = (uint32_t)__builtin_amdgcn_readlane((int)val, 63);
-
-        if (__builtin_expect(__any(e > 32u), 0)) {
-            // a pending run of >= 15 bits: emit this step serially through the literal path (wave-uniform control flow)
-            const uint32_t nb = (uint32_t)(bit_off & 31u);
-            l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
-            sink.nwords = (uint32_t)(bit_off >> 5);
-            sink.nb = (int)nb;
-            sink.acc = nb ? (uint64_t)(carry_word >> (32u - nb)) : 0u;
-            uint32_t pend = pending;
-            for (int j = 0; j < 64; ++j) {
-                const uint32_t rj = (uint32_t)__builtin_amdgcn_readlane((int)r, j);
-                const uint32_t nj = l3c::record_n(rj);
-                const uint32_t lo_j = nj ? l3c::record_top(rj) << ((32u - nj) & 31u) : 0u;
-                l3c::emit_record(lo_j, nj | (l3c::record_m(rj) << 8), pend, sink);
+        const uint32_t incl = wave_inclusive_sum(e);
+        if (lane == 63) sh.bits[wave] = incl;
+        if (__any(e > 32u) && lane == 0) sh.rare = 1u;
+        if (tid == 0) sh.buf[0] = carry_word;
+        __syncthreads();
+        if (__builtin_expect(uni(sh.rare) != 0u, 0)) {
+            // a pending run of >= 15 bits: emit this step serially through the literal path (the first wavefront, from the records)
+            if (wave == 0) {
+                const uint32_t nb = (uint32_t)(bit_off & 31u);
+                l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
+                sink.nwords = (uint32_t)(bit_off >> 5);
+                sink.nb = (int)nb;
+                sink.acc = nb ? (uint64_t)(carry_word >> (32u - nb)) : 0u;
+                uint32_t pend = pending;
+                for (int j = 0; j < kPackThreads; ++j) {
+                    const uint32_t rj = uni(sh.rec[j]);
+                    const uint32_t nj = l3c::record_n(rj);
+                    const uint32_t lo_j = nj ? l3c::record_top(rj) << ((32u - nj) & 31u) : 0u;
+                    l3c::emit_record(lo_j, nj | (l3c::record_m(rj) << 8), pend, sink);
+                }
+                if (lane == 0) {
+                    const uint64_t off = (uint64_t)sink.nwords * 32u + (uint32_t)sink.nb;
+                    sh.state[0] = pend;
+                    sh.state[1] = (uint32_t)off;
+                    sh.state[2] = (uint32_t)(off >> 32);
+                    sh.state[3] = sink.nb ? (uint32_t)(sink.acc << (32 - sink.nb)) : 0u;
+                }
             }
-            bit_off = (uint64_t)sink.nwords * 32u + (uint32_t)sink.nb;
-            carry_word = sink.nb ? (uint32_t)(sink.acc << (32 - sink.nb)) : 0u;
-            pending = pend;
+            __syncthreads();
+            pending = uni(sh.state[0]);
+            bit_off = (uint64_t)uni(sh.state[1]) | ((uint64_t)uni(sh.state[2]) << 32);
+            carry_word = uni(sh.state[3]);
+            __syncthreads();
             continue;
         }
 
-        // exclusive prefix sum of e -> bit position of every symbol inside this step's window
-        const uint32_t incl = wave_inclusive_sum(e);
-        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-        const uint32_t base = (uint32_t)(bit_off & 31u);
+        // bit position of every symbol inside this step's window: the carried bits, the wavefronts before, the lanes before
+        uint32_t base = (uint32_t)(bit_off & 31u), total = 0;
+#pragma unroll
+        for (int u = 0; u < kPackWaves; ++u) {
+            const uint32_t b_u = uni(sh.bits[u]);
+            if (u < wave) base += b_u;
+            total += b_u;
+        }
         const uint32_t pos = base + incl - e;
         // value: top n bits with the pending complements inserted after the first = top + (ones(p) << (n-1))
         const uint32_t v = emits ? top + (l3c::ones((int)p_before) << ((n - 1u) & 31u)) : 0u;
-
-        buf[lane] = lane == 0 ? carry_word : 0u;
-        if (lane < 16) buf[64 + lane] = 0u;
-        __syncthreads();
         if (e) {
             const uint32_t wi = pos >> 5;
-            const int sh = 32 - (int)(pos & 31u) - (int)e;
-            if (sh >= 0) {
-                atomicOr(&buf[wi], v << sh);
+            const int shf = 32 - (int)(pos & 31u) - (int)e;
+            if (shf >= 0) {
+                atomicOr(&sh.buf[wi], v << shf);
             } else {
-                atomicOr(&buf[wi], v >> (-sh));
-                atomicOr(&buf[wi + 1], v << (32 + sh));
+                atomicOr(&sh.buf[wi], v >> (-shf));
+                atomicOr(&sh.buf[wi + 1], v << (32 + shf));
             }
         }
         __syncthreads();
-        const uint32_t window_bits = base + total;
-        const uint32_t full = window_bits >> 5;        // complete words in the window (<= 65)
+        const uint32_t window_bits = (uint32_t)(bit_off & 31u) + total;
+        const uint32_t full = window_bits >> 5;        // complete words in the window (<= kPackThreads + 1)
         const uint32_t first_word = (uint32_t)(bit_off >> 5);
-        if ((uint32_t)lane < full) gwords[first_word + lane] = l3c::bswap32(buf[lane]);
-        if ((uint32_t)lane + 64u < full) gwords[first_word + 64 + lane] = l3c::bswap32(buf[64 + lane]);
-        carry_word = (window_bits & 31u) ? buf[full] : 0u;
+        if ((uint32_t)tid < full) gwords[first_word + tid] = l3c::bswap32(sh.buf[tid]);
+        if ((uint32_t)tid + kPackThreads < full) gwords[first_word + kPackThreads + tid] = l3c::bswap32(sh.buf[kPackThreads + tid]);
+        carry_word = (window_bits & 31u) ? uni(sh.buf[full]) : 0u;
         __syncthreads();
         bit_off += total;
-        pending = new_pending;
+        pending = pend_out;
     }
     // flush (torchac.cpp:209-219): pending + 1 complements after the quadrant bit, zero padding to a byte
-    {
+    if (wave == 0) {
         const uint32_t nb = (uint32_t)(bit_off & 31u);
         l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
         sink.nwords = (uint32_t)(bit_off >> 5);
@@ -338,15 +393,15 @@ __device__ __forceinline__ void ac_pack_body(uint32_t *buf, const uint32_t *__re
     }
 }
 
-__global__ __launch_bounds__(64) void ac_pack_kernel(const uint32_t *__restrict__ rec, int64_t n_streams, int64_t n_sym,
-                                                     const uint32_t *__restrict__ final_low, uint8_t *__restrict__ out,
-                                                     int64_t out_stride, uint32_t *__restrict__ out_nbytes) {
-    __shared__ uint32_t buf[80];   // the bits of one 64-symbol step: <= 31 carried + 64 * 32 new = 2079 bits = 65 words
-    ac_pack_body(buf, rec, n_streams, n_sym, final_low, out, out_stride, out_nbytes, blockIdx.x);
+__global__ __launch_bounds__(kPackThreads) void ac_pack_kernel(const uint32_t *__restrict__ rec, int64_t n_streams, int64_t n_sym,
+                                                                const uint32_t *__restrict__ final_low, uint8_t *__restrict__ out,
+                                                                int64_t out_stride, uint32_t *__restrict__ out_nbytes) {
+    __shared__ PackShared sh;
+    ac_pack_body(sh, rec, n_streams, n_sym, final_low, out, out_stride, out_nbytes, blockIdx.x);
 }
 
-__global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
-    __shared__ uint32_t buf[80];
+__global__ __launch_bounds__(kPackThreads) void ac_pack_groups_kernel(const AcGroup *__restrict__ groups, int n_groups) {
+    __shared__ PackShared sh;
     int64_t blk = blockIdx.x;
     int g = 0;
     for (; g < n_groups; ++g) {
@@ -355,7 +410,7 @@ __global__ __launch_bounds__(64) void ac_pack_groups_kernel(const AcGroup *__res
     }
     if (g >= n_groups) return;
     const AcGroup gr = groups[g];
-    ac_pack_body(buf, gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, gr.out, gr.out_stride, gr.out_nbytes, blk);
+    ac_pack_body(sh, gr.intervals, gr.n_streams, gr.n_sym, gr.final_low, gr.out, gr.out_stride, gr.out_nbytes, blk);
 }
 
 // ---- decoder -------------------------------------------------------------------------------------------------------
@@ -1379,7 +1434,7 @@ int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t
                        final_low);
     int rc = l3c::check_launch("ac_state_kernel");
     if (rc != L3C_OK) return rc;
-    hipLaunchKernelGGL(ac_pack_kernel, dim3((unsigned)n_streams), dim3(64), 0, l3c::as_stream(stream), intervals,
+    hipLaunchKernelGGL(ac_pack_kernel, dim3((unsigned)n_streams), dim3(kPackThreads), 0, l3c::as_stream(stream), intervals,
                        n_streams, n_sym, final_low, out, out_stride_bytes, out_nbytes);
     return l3c::check_launch("ac_pack_kernel");
 }
@@ -1423,7 +1478,7 @@ int l3c_ac_encode_groups(const l3c_ac_group *groups_host, int n_groups, void *wo
     hipLaunchKernelGGL(ac_state_groups_kernel, dim3((unsigned)state_blocks), dim3(64), 0, l3c::as_stream(stream), dev, n_groups);
     rc = l3c::check_launch("ac_state_groups_kernel");
     if (rc != L3C_OK) return rc;
-    hipLaunchKernelGGL(ac_pack_groups_kernel, dim3((unsigned)pack_blocks), dim3(64), 0, l3c::as_stream(stream), dev, n_groups);
+    hipLaunchKernelGGL(ac_pack_groups_kernel, dim3((unsigned)pack_blocks), dim3(kPackThreads), 0, l3c::as_stream(stream), dev, n_groups);
     return l3c::check_launch("ac_pack_groups_kernel");
 }
 
