@@ -79,12 +79,15 @@ int l3c_ac_intervals_from_table(const uint16_t *cdf, int64_t row_stride, int Lp,
  *            ~15 instructions per symbol): the serial interval recurrence only; every interval word is REPLACED IN PLACE
  *            by the bound right after the interval update (low' / ~high'), from which phase 2 derives what is emitted
  *   phase 2  one stream per wavefront, 64 symbols per step: records -> bits (wave scans + LDS merge), coalesced stores
- * Precondition: c_high > c_low for every symbol (strictly increasing table rows), as for the reference.
+ * Precondition: c_high > c_low for every symbol (strictly increasing table rows), as for the reference.  Intervals that violate it
+ * (the entry points cannot validate device-side intervals) produce garbage, as the reference does, but never a store outside the
+ * stream's own out_stride_bytes slot: such a stream reports out_nbytes = L3C_AC_OVERRUN when it asked for more.
  *   intervals  in/out, CLOBBERED
  *   out        uint8 [n_streams][out_stride_bytes]; out_stride_bytes % 4 == 0 and >= l3c_ac_max_bytes(n_sym)
- *   out_nbytes uint32 [n_streams]   number of bytes produced per stream
+ *   out_nbytes uint32 [n_streams]   number of bytes produced per stream, or L3C_AC_OVERRUN
  *   workspace  l3c_ac_encode_workspace_bytes(n_streams) bytes, 4-byte aligned
  */
+#define L3C_AC_OVERRUN 0xFFFFFFFFu
 int64_t l3c_ac_max_bytes(int64_t n_sym);
 int64_t l3c_ac_encode_workspace_bytes(int64_t n_streams);
 int l3c_ac_encode(uint32_t *intervals, int64_t n_streams, int64_t n_sym, uint8_t *out, int64_t out_stride_bytes,

@@ -17,3 +17,9 @@ Layout
   auto_crop.py   recursive 2x2 tiling of large images
 """
 __version__ = '0.1.0'
+
+# Before the first HIP call: give the runtime the hardware queues `Bitcoding.encode_many`'s side-by-side forward streams need, unless
+# the caller has chosen a value (helpers/runtime.py; the runtime reads the variable once, at start-up).
+from .helpers import runtime as _runtime  # noqa: E402
+
+HIP_QUEUES_CONFIGURED = _runtime.configure_hip_queues()

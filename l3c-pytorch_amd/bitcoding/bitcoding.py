@@ -114,7 +114,8 @@ class EncodedBatch(object):
         self.wait()
         tot = None
         for C, H, W, out, nbytes in self.scales:
-            t = nbytes.to(torch.int64).reshape(self.B, C).sum(dim=1)
+            t = nbytes.to(torch.int64)
+            t = torch.where(t < 0, torch.full_like(t, -(1 << 40)), t).reshape(self.B, C).sum(dim=1)    # L3C_AC_OVERRUN stays visible in the sum
             tot = t if tot is None else tot + t
         return tot
 
@@ -165,6 +166,9 @@ class EncodedBatch(object):
         sizes = torch.cat([e.file_sizes() for e in encs])
         offs = torch.cumsum(sizes, 0) - sizes
         sizes_h = sizes.cpu().numpy().astype(np.int64)          # the synchronisation: how many bytes there are
+        if (sizes_h < 0).any():     # a stream reported L3C_AC_OVERRUN (int32 -1): its intervals violated c_high > c_low
+            from .. import _lib
+            raise _lib.L3CError('range coder overrun: a stream asked for more than 16 bits per symbol (table rows not strictly increasing)')
         total = int(sizes_h.sum())
         dst = torch.empty(total, dtype=torch.uint8, device='cuda')
         first = 0
@@ -204,8 +208,15 @@ class EncodedBatch(object):
 
 
 class Bitcoding(object):
-    def __init__(self, blueprint, times=None, compare_with_theory=False, coder_cus=0, auto_recurse=0, file_writer=None):
-        """coder_cus > 0: reserve that many compute units for the range coder.  `self.compute_stream` is then a stream
+    def __init__(self, blueprint, times=None, compare_with_theory=False, coder_cus=0, auto_recurse=0, file_writer=None,
+                 coder_streams=4, forward_streams=3, decode_overlap=None, rgb_window='auto'):
+        """coder_streams: side streams the range-coder launches rotate over; forward_streams: streams `encode_many` spreads the forward
+        passes of a heterogeneous set over (used when the HIP runtime runs with >= 8 hardware queues -- helpers/runtime.py; the package
+        asks for them on import -- else one, with a warning); decode_overlap: None = the chunk-pipelined RGB decode overlaps its table
+        and decoder launches from 16 images on, True / False force either; rgb_window: 'auto' = the RGB decoder builds 64-entry table
+        rows around the mixture mean where the previous chunks of the stream say that pays, 'always' / 'never' force either form
+        (_decode_rgb_pipelined).  None of these changes a bit of a file or of a decoded image.
+        coder_cus > 0: reserve that many compute units for the range coder.  `self.compute_stream` is then a stream
         confined to the remaining CUs -- run the network under `torch.cuda.stream(bc.compute_stream)` so the MFMA-bound
         conv kernels and the latency-bound coder wavefronts never share a SIMD (they slow the coder down 2.3x).
         auto_recurse: RGB Shared baseline only -- how many times the coarsest scale is applied again (the reference evaluates it
@@ -228,6 +239,12 @@ class Bitcoding(object):
         self._coder_streams = None
         self.coder_cus = coder_cus
         self.compute_stream = None
+        self.N_SIDE_STREAMS = max(1, int(coder_streams))
+        self.N_FORWARD_STREAMS = max(1, int(forward_streams))
+        self.decode_overlap = decode_overlap
+        if rgb_window not in ('auto', 'always', 'never'):
+            raise ValueError('rgb_window must be auto, always or never')
+        self.rgb_window = rgb_window
         if coder_cus:
             from .. import _lib
             _, n_cu, _ = _lib.device_info()
@@ -236,7 +253,7 @@ class Bitcoding(object):
 
     # [measured, profiles/r02_coder_streams_small_batches.log] 8 or 12 side streams do not help with the runtime's default of four
     # hardware queues (they alias); with GPU_MAX_HW_QUEUES=8, four streams reach 27.8 / 75.7 MPix/s at 1 / 4 images per step
-    N_SIDE_STREAMS = int(os.environ.get('L3C_CODER_STREAMS', '4'))
+    N_SIDE_STREAMS = 4        # (instances: the constructor's coder_streams)
 
     def _side_stream(self):
         """Side stream for the range coder: its launches are a handful of long-running wavefronts (a lane per stream),
@@ -313,7 +330,10 @@ class Bitcoding(object):
         canvas, image b in its top-left dims[b] = (H_b, W_b) corner, zero elsewhere.  -> one EncodedBatch per image (batch size 1, its own
         shape), from that image's slices of the canvas-shaped symbols and P: byte for byte the files of the image coded alone."""
         net = self.blueprint.net
+        if self.auto_recurse:      # forward_canvas returns `scales` predictions and never applies the recursion (RGB baselines: prepare_batch)
+            raise NotImplementedError('canvas batches are not provided for auto_recurse > 0')
         sym, P, _ = net.forward_canvas(x.to('cuda', torch.float32), dims)
+        assert len(P) == self.n_predicted_scales(), (len(P), self.n_predicted_scales())
         K = net.config_ms.prob.K
         encs = []
         for b, (H, W) in enumerate(dims):
@@ -366,7 +386,7 @@ class Bitcoding(object):
         `out`: a network output for `imgs` computed earlier (avoids a second forward)."""
         return self.code([self.prepare_batch(imgs, out)])[0]
 
-    N_FORWARD_STREAMS = int(os.environ.get('L3C_FORWARD_STREAMS', '3'))     # used when the HIP runtime was given >= 8 hardware queues, see encode_many
+    N_FORWARD_STREAMS = 3     # (instances: the constructor's forward_streams) used when the HIP runtime was given >= 8 hardware queues, see encode_many
     N_CODER_GROUPS = 4
 
     def encode_many(self, batches, upload=None, on_group=None, n_groups=None, weights=None):
@@ -395,7 +415,8 @@ class Bitcoding(object):
             weights = [b.shape[0] * b.shape[2] * b.shape[3] for b in batches]
         order = sorted(range(len(batches)), key=lambda i: -weights[i])
         main = torch.cuda.current_stream()
-        if int(os.environ.get('GPU_MAX_HW_QUEUES', '4') or 4) >= 8:
+        from ..helpers import runtime
+        if runtime.forward_streams_allowed(self.N_FORWARD_STREAMS) > 1:
             if getattr(self, '_fwd_streams', None) is None:
                 self._fwd_streams = [torch.cuda.Stream() for _ in range(self.N_FORWARD_STREAMS)]
             fwd = self._fwd_streams
@@ -561,8 +582,8 @@ class Bitcoding(object):
         flags = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(C)]
         states = [[ops.ac_decode_state(B), ops.ac_decode_state(B)] for _ in range(C)]
         # the two extra steps cost more than the overlap saves while the tables are small (they grow with the batch, a decode
-        # step does not): D = 2 from 16 images on [measured at 128: 0.726 s instead of 0.825 s]; L3C_DECODE_OVERLAP=0/1 forces
-        overlap = {'0': False, '1': True}.get(os.environ.get('L3C_DECODE_OVERLAP', ''), B >= 16)
+        # step does not): D = 2 from 16 images on [measured at 128: 0.726 s instead of 0.825 s]; the constructor's decode_overlap forces
+        overlap = B >= 16 if self.decode_overlap is None else bool(self.decode_overlap)
         D = 2 if overlap else 1
         main = torch.cuda.current_stream()
         side = self._side_stream() if overlap else main

@@ -42,7 +42,8 @@ class ArithmeticCoder(object):
 
     def range_decode(self, encoded_bytes, cdf, time_logger=None):
         shape = _table_shape(cdf, self.L)
-        with (time_logger or _NullTimes()).run('ac.decode'):
+        # (the reference times BOTH directions under the key 'ac.encode', coders.py:76; consumers of its time-logger keys find the same key here)
+        with (time_logger or _NullTimes()).run('ac.encode'):
             if isinstance(cdf, CDFOut):
                 flat = torchac.decode_logistic_mixture(cdf.targets, cdf.means_c, cdf.log_scales_c, cdf.logit_probs_c_sm, encoded_bytes)
             else:

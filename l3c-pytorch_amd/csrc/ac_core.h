@@ -324,7 +324,7 @@ L3C_HD int lean_advance(uint32_t &low, uint32_t &nh, uint32_t &range, uint32_t t
     const uint32_t nh1 = top_symbol ? nh : 0u - (low + t_hi);   // ~(low - 1 + t_hi)
     const uint32_t h = ~((lo ^ nh1) | ((lo & nh1) << 1));        // role_shift: != 0 as lo < hi
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int c = __builtin_clz(h);
+    const int c = h ? __builtin_clz(h) : 31;   // (h == 0 only for a table that is not strictly increasing: such a stream runs on garbage, defined garbage)
 #else
     const int c = clz32(h) & 31;
 #endif

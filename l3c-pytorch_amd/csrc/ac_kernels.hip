@@ -89,7 +89,12 @@ __device__ __forceinline__ uint32_t pair_step(uint32_t &u, uint32_t &range, uint
     const uint32_t us = u1 << 1;
     const uint32_t zz = us & pair_partner(us);            // (low' & ~high') << 1
     const uint32_t h = ~((u1 ^ o1) | zz);
-    const int t = __builtin_clz(h);                       // == role_shift(u1, o1); h != 0 for low' < high' (v_ffbh_u32: no v_min on top)
+    // == role_shift(u1, o1).  h != 0 for low' < high'; for an interval that violates the encoder's precondition (c_high <= c_low) h may be
+    // 0, for which __builtin_clz is undefined to the COMPILER: v_ffbh_u32 returns -1 there and the shifts use its low 5 bits (the stream
+    // is then garbage, as the reference's is, but nothing the optimiser may assume is violated; phase 2 bounds its stores)
+    int t;
+    asm("v_ffbh_u32 %0, %1" : "=v"(t) : "v"(h));
+    t &= 31;
     range = ~(sum << t);                                  // == role_range of the renormalised pair
     u = (u1 << t) & 0x7FFFFFFFu;                          // == role_renorm(u1, t)
     asm volatile("" : "+v"(range));   // keep `range` a value of its own: its two halves then feed the 24-bit multiplies as SDWA selects
@@ -190,8 +195,9 @@ __global__ __launch_bounds__(64) void ac_state_groups_kernel(const AcGroup *__re
 struct GlobalWordStore {
     uint32_t *words;
     bool on;
+    uint32_t cap;   // words of the stream's output slot: nothing is ever stored beyond it (see ac_pack_body)
     __device__ __forceinline__ void operator()(uint32_t i, uint32_t w) const {
-        if (on) words[i] = w;
+        if (on && i < cap) words[i] = w;
     }
 };
 
@@ -254,6 +260,10 @@ __device__ __forceinline__ void ac_pack_body(PackShared &sh, const uint32_t *__r
                                              uint32_t *__restrict__ out_nbytes, int64_t s) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *words = reinterpret_cast<uint32_t *>(out + s * out_stride);
+    // The slot holds l3c_ac_max_bytes(n_sym) bytes: enough for every stream whose intervals satisfy c_high > c_low (<= 16 bits a symbol).
+    // Intervals that do not (the public entry points cannot validate them on the host) may ask for up to 31 bits a symbol: the stores stop
+    // at the slot's end and the stream's length is reported as L3C_AC_OVERRUN instead of writing into the next stream's slot.
+    const uint32_t cap_words = (uint32_t)(out_stride >> 2);
     gu32 *gwords = (gu32 *)words;              // see the note at gu32: exact vmcnt counts for the ring of records below
     const gu32 *grec = (const gu32 *)rec;
     uint32_t pending = 0;          // block-uniform
@@ -320,7 +330,7 @@ __device__ __forceinline__ void ac_pack_body(PackShared &sh, const uint32_t *__r
             // a pending run of >= 15 bits: emit this step serially through the literal path (the first wavefront, from the records)
             if (wave == 0) {
                 const uint32_t nb = (uint32_t)(bit_off & 31u);
-                l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
+                l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0, cap_words});
                 sink.nwords = (uint32_t)(bit_off >> 5);
                 sink.nb = (int)nb;
                 sink.acc = nb ? (uint64_t)(carry_word >> (32u - nb)) : 0u;
@@ -372,8 +382,9 @@ __device__ __forceinline__ void ac_pack_body(PackShared &sh, const uint32_t *__r
         const uint32_t window_bits = (uint32_t)(bit_off & 31u) + total;
         const uint32_t full = window_bits >> 5;        // complete words in the window (<= kPackThreads + 1)
         const uint32_t first_word = (uint32_t)(bit_off >> 5);
-        if ((uint32_t)tid < full) gwords[first_word + tid] = l3c::bswap32(sh.buf[tid]);
-        if ((uint32_t)tid + kPackThreads < full) gwords[first_word + kPackThreads + tid] = l3c::bswap32(sh.buf[kPackThreads + tid]);
+        if ((uint32_t)tid < full && first_word + tid < cap_words) gwords[first_word + tid] = l3c::bswap32(sh.buf[tid]);
+        if ((uint32_t)tid + kPackThreads < full && first_word + kPackThreads + tid < cap_words)
+            gwords[first_word + kPackThreads + tid] = l3c::bswap32(sh.buf[kPackThreads + tid]);
         carry_word = (window_bits & 31u) ? uni(sh.buf[full]) : 0u;
         __syncthreads();
         bit_off += total;
@@ -382,14 +393,14 @@ __device__ __forceinline__ void ac_pack_body(PackShared &sh, const uint32_t *__r
     // flush (torchac.cpp:209-219): pending + 1 complements after the quadrant bit, zero padding to a byte
     if (wave == 0) {
         const uint32_t nb = (uint32_t)(bit_off & 31u);
-        l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0});
+        l3c::WordSink<GlobalWordStore> sink(GlobalWordStore{words, lane == 0, cap_words});
         sink.nwords = (uint32_t)(bit_off >> 5);
         sink.nb = (int)nb;
         sink.acc = nb ? (uint64_t)(carry_word >> (32u - nb)) : 0u;
         uint32_t pend = pending;
         l3c::encode_finish(final_low[s], pend, sink);
         const uint32_t nbytes = sink.finish();
-        if (lane == 0) out_nbytes[s] = nbytes;
+        if (lane == 0) out_nbytes[s] = (uint64_t)nbytes <= (uint64_t)out_stride ? nbytes : 0xFFFFFFFFu /* L3C_AC_OVERRUN */;
     }
 }
 
@@ -1007,6 +1018,16 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
 //     instructions can name; the decoded symbol goes to lane (row in the block) of `kept` by v_writelane with M0 as the lane
 //     select (gfx9's constant bus takes one SGPR)
 // Rows: set A holds the current row on entry and the first row of the next block on exit; the loop takes two rows a turn.
+// The loop names PHYSICAL registers -- s94..s101 (allocatable on gfx950 up to s101; VCC / FLAT_SCRATCH / XNACK_MASK sit above), v96..v100,
+// M0 through s_set_gpr_idx -- so it is tied to this target: any other one must not build it silently.  tools/check_asm_prefetch.py and
+// tools/check_registers.py inspect the compiled kernel at build time; -DL3C_DECODE_ASM_LOOP=0 builds the decoder with the
+// compiler-generated symbol (lean_symbol) everywhere, bit-identical and ~1.7x slower per symbol, as the fallback.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "ac_decode_lean_kernel's hand-written loop is written for gfx950 (physical SGPR / VGPR numbers); build with -DL3C_DECODE_ASM_LOOP=0 elsewhere"
+#endif
+#ifndef L3C_DECODE_ASM_LOOP
+#define L3C_DECODE_ASM_LOOP 1
+#endif
 #define L3C_ROW_READS(R0, R1, R2, R3, ADDR)                                                                        \
     "ds_read_u16_d16_hi " R0 ", " ADDR "\n\tds_read_u16_d16_hi " R1 ", " ADDR " offset:128\n\t"                     \
     "ds_read_u16_d16_hi " R2 ", " ADDR " offset:256\n\tds_read_u16_d16_hi " R3 ", " ADDR " offset:384\n\t"
@@ -1278,7 +1299,7 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
         uint32_t x = 0;
         const bool full_block = k + 1u < n_blocks;   // a full block that does not hold the stream's last symbol
         bool done = false;
-        if constexpr (NJ == 1 || ALLVALID) {
+        if constexpr (L3C_DECODE_ASM_LOOP && (NJ == 1 || ALLVALID)) {
             // the hand-written loop, unless the bit window could run out inside the block (a symbol takes at most one word)
             if (full_block) {
                 // the bit window: a block takes at most R <= 32 words (one a symbol).  Window indices stay below 64 if the block

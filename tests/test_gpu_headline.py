@@ -26,7 +26,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import ac as oracle_ac, bitcoding as obc, net as onet  # noqa: E402
-from tests.parity_gate import group_errs as _group_errs, group_ok  # noqa: E402
+from tests.parity_gate import assert_P_truth, group_errs as _group_errs, group_ok, truth_chain, truth_errs  # noqa: E402
 
 H, W = 512, 768
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -144,6 +144,21 @@ def test_decoder_side_and_P_vs_oracle_at_768x512(oracle_out, blueprint):
         assert pr < TOL_REL, (s, pa, pr)
         for name, g in groups.items():
             assert group_ok(g), (s, name, g)
+
+
+def test_P_vs_fp64_truth_at_768x512(oracle_out, blueprint, synthetic_l3c):
+    """The accuracy gate proper (round 5, tests/parity_gate.py): P against the oracle's decoder chain evaluated in DOUBLE on the same
+    bottlenecks -- flat 1e-5 for every parameter group whose values stay below 16, 1e-6 relative for the RGB means.  The fp32
+    oracle's own distance from fp64 is recorded beside it (three-way table, as tools/parity_truth.py)."""
+    _, sd = synthetic_l3c
+    P64 = truth_chain(oracle_out.bn, sd)
+    f_prev = None
+    rec = {}
+    for s in (2, 1, 0):
+        P, f_prev = blueprint.net.get_P(s, oracle_out.bn[s + 1].cuda(), f_prev)
+        rec['scale%d' % s] = {'hip_vs_fp64': truth_errs(P.cpu(), P64[s], s), 'oracle_vs_fp64': truth_errs(oracle_out.P[s], P64[s], s)}
+        _record('truth', rec)
+        assert_P_truth(P.cpu(), P64[s], s, 'headline')
 
 
 def test_forward_P_equals_get_P_on_own_bottlenecks_at_768x512(hip_out, blueprint):

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import bitcoding as obc, net as onet  # noqa: E402
 from tests.conftest import NET_FIXTURES  # noqa: E402
-from tests.parity_gate import assert_P  # noqa: E402
+from tests.parity_gate import assert_P, assert_P_truth, truth_chain  # noqa: E402
 
 
 def _make_blueprint(cfg, sd):
@@ -87,8 +87,10 @@ def test_forward_matches_reference_fixture(golden, blueprints, l3c_checkpoint, f
         print('scale {}: max |F_enc - reference| = {:.3g}'.format(s, err))
         assert err < _tol(g['enc_F%d' % s], TOL_F), (s, err)
     f_prev = None
+    P64 = truth_chain([None] + [g['bn%d' % k] for k in (1, 2, 3)], sd)     # the same chain in double: the accuracy gate (parity_gate.py)
     for s in (2, 1, 0):
         P, f_prev = blueprint.net.get_P(s, torch.from_numpy(g['bn%d' % (s + 1)]).cuda(), f_prev)
+        assert_P_truth(P.cpu(), P64[s], s, fixture)
         Pn = P.cpu().numpy()
         if s == 0:
             Pn = Pn[:, :, ::st, ::st]
@@ -141,10 +143,12 @@ def test_forward_vs_oracle_other_sizes(blueprints, l3c_checkpoint, H, W, calibra
                                                 tol=(5e-4 if calibrated else 5e-5))
         assert (out.raw.F_enc[s].cpu().permute(0, 3, 1, 2) - ref.F_enc[s]).abs().max() < _tol(ref.F_enc[s], TOL_F), s
     f_prev = None
+    P64 = truth_chain(ref.bn, sd)
     for s in (2, 1, 0):
         P, f_prev = blueprint.net.get_P(s, ref.bn[s + 1].cuda(), f_prev)
         assert (f_prev.cpu() - ref.F_dec[s]).abs().max() < _tol(ref.F_dec[s], TOL_F), s
         assert_P(P, ref.P[s], s, (H, W, calibrated))
+        assert_P_truth(P.cpu(), P64[s], s, (H, W, calibrated))       # the accuracy gate: flat 1e-5 against fp64
         if flips == 0:
             assert torch.equal(P, out.P[s]), s
 

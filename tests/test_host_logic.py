@@ -274,3 +274,56 @@ def test_coding_targets_host_bits_equal_the_oracle():
     for x_min, x_max, L in ((0, 255, 256), (-1, 1, 25)):
         got = DiscretizedMixLogisticLoss(rgb_scale=(L == 256), x_min=x_min, x_max=x_max, L=L).coding_targets('cpu')
         assert got.numpy().tobytes() == ocdf.coding_targets(x_min, x_max, L).numpy().tobytes()
+
+
+# ---- helpers/runtime.py: hardware queues and NUMA placement (round 5) -------------------------------------------------------------
+
+def test_numa_plan_from_a_fake_sysfs(tmp_path):
+    """plan_affinity reads the GPU's NUMA node and that node's CPUs from sysfs; ranks whose GPUs hang off different nodes get
+    disjoint CPU sets; without NUMA information several ranks still get disjoint slices, a single rank stays unbound."""
+    from l3c_pytorch_amd.helpers import runtime
+    sysfs = tmp_path
+    for card, node in ((0, 0), (1, 1)):
+        d = sysfs / 'class' / 'drm' / 'card{}'.format(card) / 'device'
+        d.mkdir(parents=True)
+        (d / 'numa_node').write_text('{}\n'.format(node))
+    for node, cpus in ((0, '0-3'), (1, '4-7')):
+        d = sysfs / 'devices' / 'system' / 'node' / 'node{}'.format(node)
+        d.mkdir(parents=True)
+        (d / 'cpulist').write_text(cpus + '\n')
+    allowed = set(range(8))
+    p0 = runtime.plan_affinity(0, 2, 0, allowed=allowed, sysfs=str(sysfs))
+    p1 = runtime.plan_affinity(1, 2, 1, allowed=allowed, sysfs=str(sysfs))
+    assert p0['numa_node'] == 0 and p0['cpus'] == [0, 1, 2, 3] and p1['numa_node'] == 1 and p1['cpus'] == [4, 5, 6, 7]
+    # a device sysfs knows nothing about: an even slice per rank (disjoint), or nothing for a single rank
+    q = [runtime.plan_affinity(r, 4, 5 + r, allowed=allowed, sysfs=str(sysfs)) for r in range(4)]
+    assert [x['cpus'] for x in q] == [[0, 1], [2, 3], [4, 5], [6, 7]] and all(x['numa_node'] is None for x in q)
+    assert runtime.plan_affinity(0, 1, 9, allowed=allowed, sysfs=str(sysfs))['cpus'] is None
+    assert runtime._parse_cpulist('0-2,8,10-11') == {0, 1, 2, 8, 10, 11}
+
+
+def test_forward_streams_follow_the_hardware_queues(monkeypatch):
+    """encode_many's side-by-side forward streams need >= 8 hardware queues; with fewer it uses one stream and says so ONCE."""
+    import warnings
+    from l3c_pytorch_amd.helpers import runtime
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')
+    assert runtime.hw_queues() == 8 and runtime.forward_streams_allowed(3) == 3
+    monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
+    monkeypatch.setattr(runtime, '_warned', [False])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert runtime.forward_streams_allowed(3) == 1 and runtime.forward_streams_allowed(3) == 1
+    assert len([x for x in w if 'GPU_MAX_HW_QUEUES' in str(x.message)]) == 1
+    assert runtime.forward_streams_allowed(1) == 1
+
+
+def test_the_package_configures_the_queues_on_import():
+    """import l3c_pytorch_amd before HIP starts -> GPU_MAX_HW_QUEUES is set (8) unless the caller chose a value (a fresh interpreter)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'import os, sys; sys.path.insert(0, {!r}); import l3c_pytorch_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"))'.format(root)
+    env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
+    assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().strip() == '8'
+    env['GPU_MAX_HW_QUEUES'] = '2'
+    assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().strip() == '2'
