@@ -49,6 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
+import l3c_pytorch_amd  # noqa: E402,F401  (before the first HIP call: the package configures the runtime's hardware queues, helpers/runtime.py)
 
 H, W = 512, 768
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz

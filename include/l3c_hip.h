@@ -29,7 +29,7 @@ extern "C" {
 #define L3C_ERR_HIP (-2)
 #define L3C_ERR_UNSUPPORTED (-3)
 
-#define L3C_ABI_VERSION 2
+#define L3C_ABI_VERSION 3
 
 typedef void *l3c_stream_t;
 
@@ -134,6 +134,15 @@ int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t
  *   state_in / _out    [n_streams] x l3c_ac_decode_state_bytes(); state_in null = start of the streams; must differ
  *   final_chunk        non-zero when the streams end with this chunk (their last symbol skips the update, torchac.cpp:335-337)
  *   sym_out            stream s writes sym_out[s * sym_stride + sym_offset + i], i < n_sym
+ * WINDOW ROWS (ABI version 3; all fields NULL / 0: classic rows).  With window_stats_in set, `cdf` was built by l3c_dmll_cdf_table
+ * with the same window_stats array: stream s's rows -- at its full-size slot cdf + s * n_sym * Lp -- are 65-entry WINDOW rows around
+ * the mixture's mean when window_stats_in[s] says the stream missed at most 1/64 of the symbols two chunks earlier (a quarter of the
+ * table arithmetic and bytes of the 257-entry rows), and full rows otherwise.  A symbol outside its window makes the decoder wavefront
+ * evaluate the full row of that pixel itself from P / sym_all / targets (the table kernel's device functions: the same bits), so
+ * the decoded symbols never depend on the row form.  window_stats_out[s] receives the stream's miss count of THIS chunk (what a window
+ * would have missed when the rows were full; INT32_MAX when the stream went through the generic pass): feed it to the table call and the
+ * decode part of the chunk after the next one.  RGB scale only (Lp == 257, C == 3), one stream per image: stream s = image s of P.
+ *   P, sym_all, targets, HW, C, K, c   as for l3c_dmll_cdf_table;   pix0   first pixel of this chunk (sym_all index of symbol 0)
  */
 typedef struct {
     const uint16_t *cdf;
@@ -148,6 +157,13 @@ typedef struct {
     int final_chunk;
     int16_t *sym_out;
     int64_t sym_stride, sym_offset;
+    const int32_t *window_stats_in;
+    int32_t *window_stats_out;
+    const float *P;
+    const int16_t *sym_all;
+    const float *targets;
+    int64_t HW, pix0;
+    int C, K, c;
 } l3c_ac_decode_part;
 int64_t l3c_ac_decode_state_bytes(void);
 int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_stream_t stream);
@@ -181,9 +197,14 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
  * Decoder, fused: the uint16 table rows of channel c for pixels [pix0, pix0 + npix) of every image, straight from P and the
  * symbols of the channels decoded so far (l3c_dmll_channel_params + l3c_cdf_table_mixture in one pass; identical entries).
  *   cdf [B][npix][Lp];  not_monotone: optional flag, set (never cleared) if a row is not strictly increasing
+ *   window_stats (ABI version 3; NULL: every row a full row): int32 [B], see l3c_ac_decode_part -- image b's rows are 65-entry
+ *   window rows (entries 0..63 = cdf[w0 .. w0 + 63], entry 64 = the window's offset w0) packed from the start of its full-size slot
+ *   cdf + b * npix * Lp when window_stats[b] >= 0 and 64 * window_stats[b] <= npix; otherwise full rows whose (never read) entry Lp - 1
+ *   carries w0.  Lp must be 257.
  */
 int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
-                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, l3c_stream_t stream);
+                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, const int32_t *window_stats,
+                       l3c_stream_t stream);
 
 /*
  * Fused encoder head: straight from the network output P and the symbols to the packed coding intervals of every

@@ -45,10 +45,13 @@ class AcDecodePart(ctypes.Structure):
     """l3c_ac_decode_part (include/l3c_hip.h)."""
     _fields_ = [('cdf', c_vp), ('Lp', c_int), ('in_', c_vp), ('in_offsets', c_vp), ('in_nbytes', c_vp),
                 ('n_streams', c_i64), ('n_sym', c_i64), ('not_monotone_flag', c_vp), ('state_in', c_vp),
-                ('state_out', c_vp), ('final_chunk', c_int), ('sym_out', c_vp), ('sym_stride', c_i64), ('sym_offset', c_i64)]
+                ('state_out', c_vp), ('final_chunk', c_int), ('sym_out', c_vp), ('sym_stride', c_i64), ('sym_offset', c_i64),
+                ('window_stats_in', c_vp), ('window_stats_out', c_vp), ('P', c_vp), ('sym_all', c_vp), ('targets', c_vp),
+                ('HW', c_i64), ('pix0', c_i64), ('C', c_int), ('K', c_int), ('c', c_int)]
 
 
 EPI_RELU, EPI_RESIDUAL, EPI_PIXEL_SHUFFLE = 1, 2, 4
+ABI_VERSION = 3      # include/l3c_hip.h: L3C_ABI_VERSION (3: window rows in l3c_dmll_cdf_table / l3c_ac_decode_part)
 
 # name -> (restype, argtypes); must list every symbol include/l3c_hip.h declares (tests/test_abi.py checks)
 PROTOTYPES = {
@@ -72,7 +75,7 @@ PROTOTYPES = {
     'l3c_dmll_channel_params': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
     'l3c_cdf_table_mixture': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_vp]),
     'l3c_dmll_encode_intervals': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp]),
-    'l3c_dmll_cdf_table': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_vp, c_vp, c_vp]),
+    'l3c_dmll_cdf_table': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, c_i64, c_i64, c_int, c_vp, c_vp, c_vp, c_vp]),
     'l3c_dmll_sample': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp]),
     'l3c_dmll_nll': (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_f32, c_f32, c_int, c_vp, c_vp]),
     'l3c_conv_packed_words': (c_i64, [c_int, c_int, c_int]),
@@ -123,8 +126,8 @@ def load():
         for name, (res, args) in PROTOTYPES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
-        if lib.l3c_abi_version() != 2:
-            raise L3CError('ABI version mismatch: library {} != binding 2'.format(lib.l3c_abi_version()))
+        if lib.l3c_abi_version() != ABI_VERSION:
+            raise L3CError('ABI version mismatch: library {} != binding {}'.format(lib.l3c_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

@@ -581,6 +581,20 @@ class Bitcoding(object):
         # and a set flag is exactly what every later launch of that channel must see anyway.
         flags = [torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(C)]
         states = [[ops.ac_decode_state(B), ops.ac_decode_state(B)] for _ in range(C)]
+        # WINDOW ROWS (round 5; include/l3c_hip.h, l3c_ac_decode_part).  A full row has 257 entries although the symbol almost always
+        # lies near the mixture's mean: chunk j of a channel gets 65-entry rows around the mean for every image whose decoder missed at most
+        # 1/64 of the symbols of chunk j - 2 (the newest chunk that is certain to be complete when the tables of chunk j are built, with either
+        # schedule below), full rows otherwise and for chunks 0 and 1 -- a quarter of the table arithmetic and bytes, the symbols the
+        # same (a decoder evaluates a missed pixel's full row itself).  stats[c][j + 2] is written by chunk j's decoders, read (slot j)
+        # by chunk j's table kernel and decoders alike; -1 = unknown = full rows.  rgb_window = 'always' / 'never' (tests) force a form.
+        n_ch = len(bounds)
+        if self.rgb_window == 'auto':
+            stats = torch.full((C, n_ch + 2, B), -1, dtype=torch.int32, device='cuda')
+        elif self.rgb_window == 'always':
+            stats = torch.zeros((C, n_ch + 2, B), dtype=torch.int32, device='cuda')
+        else:
+            stats = None
+        scratch = torch.empty(B, dtype=torch.int32, device='cuda') if self.rgb_window == 'always' else None
         # the two extra steps cost more than the overlap saves while the tables are small (they grow with the batch, a decode
         # step does not): D = 2 from 16 images on [measured at 128: 0.726 s instead of 0.825 s]; the constructor's decode_overlap forces
         overlap = B >= 16 if self.decode_overlap is None else bool(self.decode_overlap)
@@ -598,13 +612,16 @@ class Bitcoding(object):
             parts = []
             for c, j in active:
                 p0, n = bounds[j]
-                table = ops.dmll_cdf_table(P, sym, targets, C, K, True, c, p0, n, flags[c])
+                win = None
+                if stats is not None:     # (in, out, ...): 'always' reads zeros and writes to a scratch row
+                    win = (stats[c, j], scratch if scratch is not None else stats[c, j + 2], P, sym, targets, p0, C, K, c)
+                table = ops.dmll_cdf_table(P, sym, targets, C, K, True, c, p0, n, flags[c], window_stats=win[0] if win else None)
                 if overlap:
                     table.record_stream(side)
                 buf, offs, lens = packed[c]
                 parts.append(ops.ac_decode_part(table.reshape(B * n, -1), buf, offs, lens, B, n, flags[c],
                                                 states[c][(j + 1) & 1] if j else None, states[c][j & 1],
-                                                j == len(bounds) - 1, sym, C * HW, c * HW + p0))   # image b, channel c
+                                                j == len(bounds) - 1, sym, C * HW, c * HW + p0, window=win))   # image b, channel c
             if overlap:
                 side.wait_stream(main)                   # the tables of this step
                 with torch.cuda.stream(side):
@@ -614,6 +631,7 @@ class Bitcoding(object):
                 ops.ac_decode_chunks(parts)
         if overlap:
             main.wait_stream(side)
+        self.last_rgb_window_stats = stats      # (development / tests: misses per channel, chunk + 2, image)
         return sym
 
     # ---- reference API: one image <-> one file -----------------------------------------------------------------------

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "ac_core.h"
+#include "dmll_core.h"
 #include "l3c_common.h"
 
 namespace {
@@ -758,6 +759,66 @@ struct DecodeState {
 };
 static_assert(sizeof(DecodeState) == 32, "l3c_ac_decode_state_bytes");
 
+// ---- window rows (round 5; csrc/dmll_core.h) --------------------------------------------------------------------------------
+// The RGB decoder's table rows come in two forms per (image, chunk): 65-entry WINDOW rows around the mixture's mean or full 257-entry
+// rows; which one is a pure function of the miss count the stream's decoder wrote two chunks earlier (l3c::use_window), evaluated
+// alike by the table kernel and here.  A symbol outside its window -- x' = 0 or 63 where that is not the alphabet's end -- makes the
+// wavefront evaluate the pixel's full row itself (window_full_row: the table kernel's device functions, the same bits) and rank
+// against that.  Window streams are decoded by the <1, ..., WINDOW> instantiations (one row register, like the bottleneck scales),
+// full-row streams by the classic ones; both are launched over the same grid and a block leaves at once when the stream is not its kind.
+struct WindowCtx {
+    const int32_t *stats_in;       // [n_streams] misses two chunks ago (negative: unknown); nullptr: no window rows at all
+    int32_t *stats_out;            // [n_streams] misses of this chunk
+    const float *P;                // [B][HW][4 C K]
+    const int16_t *sym;            // [B][C][HW]: the channels decoded so far
+    const float *targets;          // [257]
+    int64_t HW, pix0;
+    int C, K, c;
+};
+
+__device__ __forceinline__ uint32_t lds_read_u16_now(uint32_t addr) {
+    uint32_t v;
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// All 256 entries of the full row of pixel n of image b (lane l: entries l, l + 64, l + 128, l + 192), by the wavefront itself: every
+// lane walks the K components (redundantly: the parameters are wave-uniform) and sums its four entries in the table kernel's order.
+__device__ __forceinline__ Regs<4> window_full_row(const WindowCtx &w, int64_t b, int64_t n, int lane) {
+    const int C = w.C, K = w.K, c = w.c;
+    const float *px = w.P + (b * w.HW + n) * (int64_t)(4 * C * K);
+    auto get = [&](int ch) { return px[ch]; };
+    float x0 = 0.f, x1 = 0.f;
+    if (c > 0) {
+        x0 = (float)w.sym[(b * C + 0) * w.HW + n];
+        if (c > 1) x1 = (float)w.sym[(b * C + 1) * w.HW + n];
+    }
+    const l3c::MixStats st = l3c::mix_stats(get, C, K, c);
+    const float t0 = w.targets[lane], t1 = w.targets[lane + 64], t2 = w.targets[lane + 128], t3 = w.targets[lane + 192];
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        const l3c::MixComponent m = l3c::mix_component(get, st, C, K, 1, c, k, x0, x1);
+        const float inv = expf(-m.log_sigma);
+        a0 = a0 + l3c::cdf_term(m.pi, m.mu, inv, t0);
+        a1 = a1 + l3c::cdf_term(m.pi, m.mu, inv, t1);
+        a2 = a2 + l3c::cdf_term(m.pi, m.mu, inv, t2);
+        a3 = a3 + l3c::cdf_term(m.pi, m.mu, inv, t3);
+    }
+    const float scale = (float)(65536 - 256);
+    return Regs<4>{l3c::cdf_quantise(a0, scale, lane), l3c::cdf_quantise(a1, scale, lane + 64), l3c::cdf_quantise(a2, scale, lane + 128),
+                   l3c::cdf_quantise(a3, scale, lane + 192)};
+}
+
+// entries 0 .. 255 strictly increasing?  (the table kernel has only checked the window's part of this row)
+__device__ __forceinline__ bool full_row_monotone(const Regs<4> &r, int lane) {
+    const uint32_t na = (uint32_t)__shfl_down((int)r.a, 1, 64), nb = (uint32_t)__shfl_down((int)r.b, 1, 64);
+    const uint32_t nc = (uint32_t)__shfl_down((int)r.c, 1, 64), nd = (uint32_t)__shfl_down((int)r.d, 1, 64);
+    bool bad = lane < 63 && (!(r.a < na) || !(r.b < nb) || !(r.c < nc) || !(r.d < nd));
+    const uint32_t b0 = lane_read(r.b, 0), c0 = lane_read(r.c, 0), d0 = lane_read(r.d, 0);
+    bad = bad || (lane == 63 && (!(r.a < b0) || !(r.b < c0) || !(r.c < d0)));
+    return !__any(bad);
+}
+
 struct DecodeArgs {
     const uint16_t *cdf;           // rows of THIS chunk: [n_streams][n_sym][Lp]
     int Lp;
@@ -775,6 +836,7 @@ struct DecodeArgs {
     DecodeState *state_out;        // null: not needed
     int16_t *sym_out;
     int64_t sym_stride, sym_offset;   // stream s writes sym_out[s * sym_stride + sym_offset + i]
+    WindowCtx win;                 // window rows (round 5): win.stats_in == nullptr -> classic rows
 };
 
 // The GENERIC decoder: the reference's arithmetic literally (decode_symbol), for every stream when the table is not validated,
@@ -787,15 +849,21 @@ struct DecodeArgsPack {
     DecodeArgs part[N];
 };
 
-template <int NJ, int IPB_ = (NJ == 1 ? 3 : 9)>
+// WINDOW: the instantiation for the streams whose rows of this chunk are window rows (NJ == 1): every symbol is ranked inside its window;
+// a miss -- and, when the table is not validated, EVERY symbol -- goes through the pixel's full row, evaluated here, with the reference's
+// literal arithmetic (decode_symbol<4>), so that this pass decodes what the classic generic pass decodes from full rows.
+template <int NJ, int IPB_ = (NJ == 1 ? 3 : 9), bool WINDOW = false>
 __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack pack) {
+    static_assert(!WINDOW || NJ == 1, "window rows fill one row register");
     using C = RingCfg<NJ, IPB_>;
     const DecodeArgs &a = pack.part[blockIdx.y];
     if ((int64_t)blockIdx.x >= a.n_streams) return;
     const uint16_t *cdf = a.cdf;
-    const int Lp = a.Lp;
     const int64_t table_bytes = a.table_bytes;
     const uint32_t n_sym = a.n_sym;
+    const bool has_win = a.win.stats_in != nullptr;
+    if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x], (long long)n_sym))) return;   // not this kernel's kind of stream
+    const int Lp = WINDOW ? l3c::kWinLp : a.Lp;
     const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
     const int64_t s = blockIdx.x;
@@ -805,7 +873,7 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
     const uint32_t R = (uint32_t)ring_rows_per_block(Lp, C::BLOCK_BYTES);
     const uint32_t n_blocks = (n_sym + R - 1u) / R;
     const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
-    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
+    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * ((uint64_t)a.Lp * 2u);   // this stream's first row (its full-size slot)
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
     int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
     if (!a.force && validated && dst[0] != (int16_t)-1) return;   // decoded by the fast pass (ac_decode_lean_kernel)
@@ -871,12 +939,37 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
             regs_mask(row, lane, top);
             lds_row_issue(i == i_cross ? addr_cross : addr_next, pending);   // row i + 1 (past the end: never used)
             addr_next += row_bytes;
-            const uint32_t x = decode_symbol<NJ>(row, low, high, value, src, top, validated, i != no_advance);
-            keep_symbol(dst, i, n_sym, x, lane, kept);
-            lds_row_take(row, pending);   // the only take of the loop, on every path (tools/check_asm_prefetch.py)
+            uint32_t x = 0;
+            if constexpr (WINDOW) {
+                bool need_full = !validated;
+                if (validated) {   // rank inside the window first
+                    const uint32_t xw = decode_symbol<1>(row, low, high, value, src, top, true, false);   // no advance: the state is untouched
+                    // the row's entry 64: its window offset (the read also lands the prefetched row; lds_row_take below still moves it)
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u16_now(
+                        block_addr(k) - (uint32_t)lane * 2u + (i - k * R) * row_bytes + 2u * (uint32_t)l3c::kWinTop + 2u));
+                    if (l3c::window_miss(xw, w0)) {
+                        need_full = true;
+                    } else {
+                        decode_symbol<1>(row, low, high, value, src, top, true, i != no_advance);
+                        x = w0 + xw;
+                    }
+                }
+                lds_row_take(row, pending);   // (before the long path: no LDS read in flight while the full row is evaluated)
+                if (need_full) {
+                    const Regs<4> full = window_full_row(a.win, s, a.win.pix0 + (int64_t)i, lane);
+                    x = decode_symbol<4>(full, low, high, value, src, 255, validated && full_row_monotone(full, lane), i != no_advance);
+                }
+                keep_symbol(dst, i, n_sym, x, lane, kept);
+            } else {
+                x = decode_symbol<NJ>(row, low, high, value, src, top, validated, i != no_advance);
+                keep_symbol(dst, i, n_sym, x, lane, kept);
+                lds_row_take(row, pending);   // the only take of the loop, on every path (tools/check_asm_prefetch.py)
+            }
         }
     }
     if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.pos, {0u, 0u, 0u, 0u}};
+    // a stream that needed this pass reports no usable statistics: the chunk after the next one gets full rows
+    if (has_win && a.win.stats_out && lane == 0) a.win.stats_out[s] = 0x7FFFFFFF;
 }
 
 // ---- the lean fast decoder (round 4) --------------------------------------------------------------------------------------
@@ -991,6 +1084,45 @@ __device__ __forceinline__ void lean_symbol_body(const RowHi<NJ> &row, const Val
         }
     }
 }
+// A symbol of a WINDOW row (csrc/dmll_core.h; entries 0 .. 63 in the high half-words like every lean row; w0: the window's offset, the
+// row's entry 64, read from the ring by the caller).
+// Ranked inside the window; unless that is a miss, the state advances as for a 64-symbol alphabet whose top symbol is entry 63, and
+// x = w0 + x'.  On a MISS nothing is touched and true is returned: the caller evaluates the pixel's full row (once the prefetched LDS
+// reads have landed) and decodes the symbol from that with lean_symbol<4>.
+template <bool FULLRANGE>
+__device__ __forceinline__ bool lean_symbol_window_body(const RowHi<1> &row, uint32_t w0, bool advance, LeanState &st, WaveBits &src, uint32_t &x) {
+    const uint32_t d = (uint32_t)(st.vb >> 32) - st.low;
+    RowHi<1> t;
+    if (FULLRANGE) t = row;
+    else t = row_mul_hi(row, st.range + 1u);
+    const uint32_t rank = count_le(t.a, d);
+    uint32_t x1 = rank > 1u ? rank : 1u;
+    asm("" : "+s"(x1));
+    const uint32_t xw = x1 - 1u;
+    if (l3c::window_miss(xw, w0) && d <= st.range) return true;   // (a value outside [low, high] is not a miss: it marks the stream below)
+    st.bad |= d > st.range ? 1u : 0u;
+    uint32_t t_lo, t_hi;
+    row_fetch2(t, xw, x1, t_lo, t_hi);
+    x = w0 + xw;
+    if (advance) {
+        uint32_t msb;
+        const int c = l3c::lean_advance(st.low, st.nh, st.range, t_lo, t_hi, xw == (uint32_t)l3c::kWinTop, msb);
+        st.vb = (((st.vb & 0xFFFFFFFF00000000ull) | (st.buf >> 32)) << c) ^ ((uint64_t)msb << 32);
+        st.buf <<= c;
+        st.nbits -= (uint32_t)c;
+        if (__builtin_expect(st.nbits < 32u, 0)) {
+            st.buf |= (uint64_t)src.word(st.widx) << (32u - st.nbits);
+            st.widx += 1u;
+            st.nbits += 32u;
+        }
+    }
+    return false;
+}
+__device__ __forceinline__ bool lean_symbol_window(const RowHi<1> &row, uint32_t w0, bool advance, LeanState &st, WaveBits &src, uint32_t &x) {
+    if (__builtin_expect(st.range == 0xFFFFFFFFu, 0)) return lean_symbol_window_body<true>(row, w0, advance, st, src, x);
+    return lean_symbol_window_body<false>(row, w0, advance, st, src, x);
+}
+
 template <int NJ, bool ALLVALID>
 __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLanes<NJ> &valid, uint32_t top, bool advance,
                                             LeanState &st, WaveBits &src, uint32_t &x) {
@@ -1168,15 +1300,22 @@ __device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, const V
     lean_block_uniform(st, wrel, minspan, value);
 }
 
-template <int NJ, bool ALLVALID, int IPB_ = (NJ == 1 ? 3 : 9)>
+// WINDOW (round 5): the instantiation for streams whose rows of this chunk are 65-entry window rows -- one row register, the bottleneck
+// scales' loop.  The hand-written loop runs a block as if no symbol could miss; afterwards every lane compares ITS row's rank with its
+// row's window offset (one LDS read per block): a real miss in the block -- the first one is always seen, the state before it is
+// valid -- sends the block through the careful symbols below, which evaluate a missed pixel's full row in the wavefront.
+template <int NJ, bool ALLVALID, int IPB_ = (NJ == 1 ? 3 : 9), bool WINDOW = false>
 __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack pack) {
+    static_assert(!WINDOW || (NJ == 1 && ALLVALID), "window rows fill one row register, all 64 lanes hold entries");
     using C = RingCfg<NJ, IPB_>;
     const DecodeArgs &a = pack.part[blockIdx.y];
     if ((int64_t)blockIdx.x >= a.n_streams) return;
     const uint16_t *cdf = a.cdf;
-    const int Lp = a.Lp;
     const int64_t table_bytes = a.table_bytes;
     const uint32_t n_sym = a.n_sym;
+    const bool has_win = a.win.stats_in != nullptr;
+    if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x], (long long)n_sym))) return;   // not this kernel's kind of stream
+    const int Lp = WINDOW ? l3c::kWinLp : a.Lp;
     const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
     __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
     const int64_t s = blockIdx.x;
@@ -1186,7 +1325,7 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
     const uint32_t R = (uint32_t)ring_rows_per_block(Lp, C::BLOCK_BYTES) & ~1u;   // even: the loop below takes rows in pairs
     const uint32_t n_blocks = (n_sym + R - 1u) / R;
     const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
-    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * row_bytes;            // this stream's first row
+    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * ((uint64_t)a.Lp * 2u);   // this stream's first row (its full-size slot)
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
     int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
     if (!validated) {   // not a table for the fast path: leave the whole chunk to the generic pass
@@ -1221,10 +1360,11 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
                                              (__attribute__((address_space(3))) void *)(slot + q * 1024), 16, 0, 0);
         }
     };
-    auto block_addr = [&](uint32_t k) -> uint32_t {   // LDS byte address of this lane's first entry of row k * R
+    auto block_base = [&](uint32_t k) -> uint32_t {   // LDS byte address of entry 0 of row k * R
         const uint64_t b = stream0 + (uint64_t)k * R * row_bytes;
-        return ring_base + (k % C::NB) * C::BLOCK_BYTES + (uint32_t)(b & 15u) + (uint32_t)lane * 2u;
+        return ring_base + (k % C::NB) * C::BLOCK_BYTES + (uint32_t)(b & 15u);
     };
+    auto block_addr = [&](uint32_t k) -> uint32_t { return block_base(k) + (uint32_t)lane * 2u; };   // ... of this lane's first entry
 
     WaveBits src;
     const uint32_t *words = reinterpret_cast<const uint32_t *>(a.in + a.in_offsets[s]);
@@ -1281,7 +1421,31 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
     if constexpr (NJ == 1) valid = valid_lanes1(lane, (int)top);
     else valid = valid_lanes4(lane, (int)top);
     int kept = 0;
-#define L3C_LEAN_SYMBOL(ROW, ADVANCE) lean_symbol<NJ, ALLVALID>(ROW, valid, top, ADVANCE, st, src, x);
+    uint32_t misses = 0;   // WINDOW: symbols that fell outside their window; classic rows of a windowed part: symbols a window would have missed
+    bool miss = false;
+    // One careful symbol.  WINDOW: a miss leaves the state untouched (L3C_LEAN_FIXUP then decodes the symbol from the pixel's full row,
+    // AFTER the wait for the prefetched row: no LDS read is in flight while that long path runs)
+#define L3C_LEAN_SYMBOL(ROW, ADVANCE, J)                                                                                   \
+    if constexpr (WINDOW) {  /* (the row's entry 64: its window offset; the read also lands the prefetched row early) */   \
+        const uint32_t w0_j = lds_read_u16_now(block_base(k) + (uint32_t)(J) * row_bytes + 2u * (uint32_t)l3c::kWinTop + 2u); \
+        miss = lean_symbol_window(ROW, (uint32_t)__builtin_amdgcn_readfirstlane((int)w0_j), ADVANCE, st, src, x);           \
+    } else {                                                                                                               \
+        lean_symbol<NJ, ALLVALID>(ROW, valid, top, ADVANCE, st, src, x);                                                   \
+    }
+#define L3C_LEAN_FIXUP(J, ADVANCE)                                                                                         \
+    if constexpr (WINDOW) {                                                                                                \
+        if (__builtin_expect(miss, 0)) {                                                                                   \
+            const Regs<4> full = window_full_row(a.win, s, a.win.pix0 + (int64_t)(i0 + (J)), lane);                        \
+            if (full_row_monotone(full, lane)) {                                                                           \
+                const RowHi<4> fh{full.a << 16, full.b << 16, full.c << 16, full.d << 16};                                 \
+                lean_symbol<4, true>(fh, ValidLanes<4>{~0ull, ~0ull, ~0ull, ~0ull}, 255u, ADVANCE, st, src, x);            \
+            } else {                                                                                                       \
+                st.bad = 1u;   /* a row the fast pass must not rank: the generic pass decodes this chunk */                \
+            }                                                                                                              \
+            misses += 1u;                                                                                                  \
+        }                                                                                                                  \
+    }                                                                                                                      \
+    kept = lane == (int)(J) ? (int)x : kept;
     for (uint32_t k = 0; k < n_blocks; ++k) {
         // Request block k + NB - 1 (its slot held block k - 1, fully consumed), then make sure block k + 1 -- whose first row
         // is prefetched at the end of this block -- has landed: only the two newest requests may stay in flight.
@@ -1316,7 +1480,16 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
                 lean_block_asm(rowA, rowB, valid, st, wrel, minspan, window, kept, addr_next, addr_cross, row_bytes, R, top);
                 st.widx = src.base + wofs + wrel;
                 done = minspan != 0u && st.bad == 0u;
-                if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range or a bad value: again, the careful way
+                if constexpr (WINDOW) {
+                    // lane j holds the rank x' of row j: a real miss?  (the loop ran on as if not -- everything after the first miss is
+                    // garbage, but the first one is seen: the state before it was valid.)  None: the symbols are w0 + x'.
+                    const uint32_t r_l = (uint32_t)lane < R ? (uint32_t)lane : R - 1u;
+                    const uint32_t w0_l = lds_read_u16_now(block_base(k) + r_l * row_bytes + 2u * (uint32_t)l3c::kWinTop + 2u);   // entry 64
+                    const bool miss_l = (uint32_t)lane < R && l3c::window_miss((uint32_t)kept, w0_l);
+                    done = done && __builtin_amdgcn_ballot_w64(miss_l) == 0ull;
+                    if (done) kept += (int)w0_l;
+                }
+                if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range, a bad value or a window miss: again, the careful way
                     st = saved;
                     row_hi_issue(block_addr(k), rowA);
                     row_hi_wait(rowA);
@@ -1328,29 +1501,29 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
             for (uint32_t j = 0; j < R; j += 2u) {
                 row_hi_issue(addr_next, rowB);
                 addr_next += row_bytes;
-                L3C_LEAN_SYMBOL(rowA, true)
-                kept = lane == (int)j ? (int)x : kept;
+                L3C_LEAN_SYMBOL(rowA, true, j)
                 row_hi_wait(rowB);
+                L3C_LEAN_FIXUP(j, true)
                 row_hi_issue(j + 2u == R ? addr_cross : addr_next, rowA);   // the row after the block's last lives in block k + 1
                 addr_next += row_bytes;
-                L3C_LEAN_SYMBOL(rowB, true)
-                kept = lane == (int)(j + 1u) ? (int)x : kept;
+                L3C_LEAN_SYMBOL(rowB, true, j + 1u)
                 row_hi_wait(rowA);
+                L3C_LEAN_FIXUP(j + 1u, true)
             }
         } else {                   // the last block: ragged, and its last symbol may not advance the state
             for (uint32_t j = 0; j < rows; ++j) {
                 const bool advance = i0 + j != no_advance;
                 if (j & 1u) {
                     row_hi_issue(addr_next, rowA);   // past the stream's last row: never used
-                    L3C_LEAN_SYMBOL(rowB, advance)
+                    L3C_LEAN_SYMBOL(rowB, advance, j)
                     row_hi_wait(rowA);
                 } else {
                     row_hi_issue(addr_next, rowB);
-                    L3C_LEAN_SYMBOL(rowA, advance)
+                    L3C_LEAN_SYMBOL(rowA, advance, j)
                     row_hi_wait(rowB);
                 }
                 addr_next += row_bytes;
-                kept = lane == (int)j ? (int)x : kept;
+                L3C_LEAN_FIXUP(j, advance)
             }
         }
         if (__builtin_expect(st.bad != 0u, 0)) {
@@ -1360,11 +1533,23 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
             if (lane == 0) dst[0] = (int16_t)-1;
             return;
         }
+        if constexpr (!WINDOW && NJ == 4) {
+            // full rows of a windowed part: what would a window have missed?  The (never decoded) entry Lp - 1 of row j carries its offset
+            // (l3c_dmll_cdf_table); block k is still in its ring slot
+            if (has_win) {
+                const uint32_t r_l = (uint32_t)lane < rows ? (uint32_t)lane : rows - 1u;
+                const uint32_t w0_l = lds_read_u16_now(block_base(k) + r_l * row_bytes + (uint32_t)(Lp - 1) * 2u);
+                const bool m_l = (uint32_t)lane < rows && l3c::window_would_miss((uint32_t)kept & 0xFFFFu, w0_l);
+                misses += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m_l));
+            }
+        }
         if ((uint32_t)lane < rows) dst[i0 + (uint32_t)lane] = (int16_t)kept;
     }
 #undef L3C_LEAN_SYMBOL
+#undef L3C_LEAN_FIXUP
     if (a.state_out && lane == 0)
         a.state_out[s] = DecodeState{st.low, ~st.nh, (uint32_t)(st.vb >> 32), st.widx * 32u - st.nbits, {0u, 0u, 0u, 0u}};
+    if (has_win && a.win.stats_out && lane == 0) a.win.stats_out[s] = (int32_t)(misses < 0x7FFFFFFFu ? misses : 0x7FFFFFFFu);
 }
 
 __global__ __launch_bounds__(256) void check_monotone_kernel(const uint16_t *__restrict__ cdf, int64_t n_rows, int Lp,
@@ -1396,9 +1581,16 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
     // wide alphabet: the small ring from 48 streams per launch on (a batch of 16 images: the decoders then share the machine with the
     // table kernel of the next chunk step); the result does not depend on the ring size
     const bool crowd = max_streams * n_parts >= 48;
+    bool any_win = false;   // some part's table may hold window rows: their streams are decoded by the <1, ..., WINDOW> instantiations
+    for (int i = 0; i < n_parts; ++i) any_win = any_win || pack.part[i].win.stats_in != nullptr;
     if (fast_pass) {   // streams that leave the fast path (or all, if the table is not validated) mark themselves
         bool full = true;   // every part codes the 256-symbol alphabet: all entries of the four row registers are table entries
         for (int i = 0; i < n_parts; ++i) full = full && pack.part[i].Lp == 257;
+        if (any_win) {
+            hipLaunchKernelGGL((ac_decode_lean_kernel<1, true, 3, true>), grid, block, 0, st, pack);
+            const int rcw = l3c::check_launch("ac_decode_lean_kernel<window>");
+            if (rcw != L3C_OK) return rcw;
+        }
         if (small) hipLaunchKernelGGL((ac_decode_lean_kernel<1, false>), grid, block, 0, st, pack);
         else if (crowd && full) hipLaunchKernelGGL((ac_decode_lean_kernel<4, true, 3>), grid, block, 0, st, pack);
         else if (crowd) hipLaunchKernelGGL((ac_decode_lean_kernel<4, false, 3>), grid, block, 0, st, pack);
@@ -1408,6 +1600,11 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
         if (rc != L3C_OK) return rc;
     }
     for (int i = 0; i < n_parts; ++i) pack.part[i].force = fast_pass ? 0 : 1;
+    if (any_win) {
+        hipLaunchKernelGGL((ac_decode_ring_kernel<1, 3, true>), grid, block, 0, st, pack);
+        const int rcw = l3c::check_launch("ac_decode_ring_kernel<window>");
+        if (rcw != L3C_OK) return rcw;
+    }
     if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1>), grid, block, 0, st, pack);
     else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, 3>), grid, block, 0, st, pack);
     else hipLaunchKernelGGL((ac_decode_ring_kernel<4>), grid, block, 0, st, pack);
@@ -1574,6 +1771,13 @@ int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_strea
         a.sym_out = q.sym_out;
         a.sym_stride = q.sym_stride;
         a.sym_offset = q.sym_offset;
+        if (q.window_stats_in) {
+            L3C_REQUIRE(q.Lp == 257 && q.C == 3 && q.K > 0 && q.K <= 16 && q.c >= 0 && q.c < 3, "window rows: RGB scale only (Lp 257, C 3, K <= 16)");
+            L3C_REQUIRE(q.P && q.targets && (q.c == 0 || q.sym_all), "window rows: P, targets and the decoded channels are needed to evaluate a missed row");
+            L3C_REQUIRE(q.not_monotone_flag, "window rows: the table's validity flag is required");
+            L3C_REQUIRE(q.HW > 0 && q.pix0 >= 0 && q.pix0 + q.n_sym <= q.HW, "window rows: chunk outside the image");
+            a.win = WindowCtx{q.window_stats_in, q.window_stats_out, q.P, q.sym_all, q.targets, q.HW, q.pix0, q.C, q.K, q.c};
+        }
     }
     return launch_ring_decode(pack, n_parts, /*fast_pass=*/parts[0].not_monotone_flag != nullptr, l3c::as_stream(stream));
 }

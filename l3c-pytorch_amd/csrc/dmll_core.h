@@ -49,5 +49,104 @@ __device__ __forceinline__ float sigmoid_sat(float a) {
     return sigmoid_f(a);   // also NaN
 }
 
+// ---- the mixture of one (pixel, channel): shared by the table / interval kernels (csrc/dmll_kernels.hip) and by the range decoder,
+// which evaluates a whole row itself when a symbol falls outside the 64-entry window row it was handed (csrc/ac_kernels.hip).  ONE
+// definition, every operation an individually rounded fp32 one in a fixed order (-ffp-contract=off, K walked sequentially): whoever
+// evaluates an entry gets the same bits.
+//   pi  = exp(l - max) / sum_k exp(l - max)            F.softmax(dim=K)
+//   mu' = mu (+ sigmoid(lam) * x_prev ...)              logistic_mixture.py:262-272
+//   ls  = max(log_sigma, -7)                            :260
+//   cdf(l) = sum_k pi_k * sigmoid((t_l - mu'_k) * exp(-ls_k))   sequential k, mul then add   (torchac.py:181-200)
+//   entry  = uint16(rint(cdf * (65536 - (Lp-1))) + l)            round-half-even, wraps mod 2^16 (torchac.py:203-213)
+// Accessor concept: float operator()(int ch) -- channel `ch` (0..Kp-1) of the current pixel.
+constexpr float kLogScalesMin = -7.0f;
+
+struct MixStats {
+    float max_logit, denom;
+};
+
+template <class Get>
+__device__ __forceinline__ MixStats mix_stats(Get get, int C, int K, int c) {
+    MixStats s;
+    s.max_logit = get(c * K);
+    for (int k = 1; k < K; ++k) s.max_logit = fmaxf(s.max_logit, get(c * K + k));
+    s.denom = 0.0f;
+    for (int k = 0; k < K; ++k) s.denom = s.denom + expf(get(c * K + k) - s.max_logit);
+    return s;
+}
+
+struct MixComponent {
+    float pi, mu, log_sigma;
+};
+
+// x0, x1: actual values of the previously coded channels (RGB scale only, c > 0).
+// e_k = expf(logit_k - max): the softmax numerator.  Callers that have just computed it for the denominator pass it in (the
+// same operation on the same operands: the same bits) instead of paying a second expf.
+template <class Get>
+__device__ __forceinline__ MixComponent mix_component_e(Get get, const MixStats &st, float e_k, int C, int K, int rgb, int c, int k,
+                                                        float x0, float x1) {
+    const int CK = C * K;
+    MixComponent m;
+    m.pi = e_k / st.denom;
+    m.mu = get(CK + c * K + k);
+    m.log_sigma = fmaxf(get(2 * CK + c * K + k), kLogScalesMin);
+    if (rgb && c == 1) {
+        m.mu = m.mu + sigmoid_f(get(3 * CK + k)) * x0;
+    } else if (rgb && c == 2) {
+        const float a = sigmoid_f(get(3 * CK + K + k)) * x0;
+        const float b = sigmoid_f(get(3 * CK + 2 * K + k)) * x1;
+        m.mu = m.mu + (a + b);
+    }
+    return m;
+}
+
+template <class Get>
+__device__ __forceinline__ MixComponent mix_component(Get get, const MixStats &st, int C, int K, int rgb, int c, int k,
+                                                      float x0, float x1) {
+    return mix_component_e(get, st, expf(get(c * K + k) - st.max_logit), C, K, rgb, c, k, x0, x1);
+}
+
+__device__ __forceinline__ float cdf_term(float pi, float mu, float inv_sigma, float target) {
+    return pi * sigmoid_sat((target - mu) * inv_sigma);
+}
+
+__device__ __forceinline__ uint32_t cdf_quantise(float cdf, float scale, int l) {
+    return (uint32_t)((int)rintf(cdf * scale) + l) & 0xFFFFu;
+}
+
+// ---- window rows (round 5): the RGB decoder's 64-entry table rows ------------------------------------------------------------
+// A full row has Lp = 257 entries; the symbol almost always lies near the mixture's mean.  A WINDOW row has kWinLp = 65 uint16:
+//     e[j] = cdf[w0 + j], j = 0 .. 63            e[64] = w0 (the window's offset, 0 .. kWinMaxOffset)
+// (cdf[0] is NOT zero in general: it is the mixture's mass below the first bin edge, torchac.py:181-213 -- so e[0] must be the true entry.)
+// Ranked like a 64-symbol alphabet -- x' = max(#{j: e[j] <= count}, 1) - 1, as every decoder here ranks -- it yields
+//     1 <= x' <= 62           symbol w0 + x', interval [e[x'], e[x' + 1]) -- exactly the full row's
+//     x' == 0                 symbol <= w0: taken as exact (symbol 0, interval [e[0], e[1])) iff w0 == 0, otherwise a MISS
+//     x' == 63                symbol >= w0 + 63: exact (the top symbol 255, interval [e[63], 2^16)) iff w0 == kWinMaxOffset, else a MISS
+// On a miss the decoder evaluates the full row of that pixel itself (the functions above: the same bits).  Which form the rows of an
+// image's chunk have is a pure function of the miss count the decoder reported two chunks earlier (see use_window).
+constexpr int kWinLp = 65;
+constexpr int kWinTop = 63;
+constexpr int kWinMaxOffset = 192;      // 256 - 64
+
+__host__ __device__ __forceinline__ bool use_window(int prev_misses, long long n_sym) {
+    return prev_misses >= 0 && (long long)prev_misses * 64 <= n_sym;     // unknown (negative) or > 1/64 of the symbols missed: full rows
+}
+
+// offset of the window around the mixture's mean (sum_k pi_k mu_k, sequential): symbols w0 + 1 .. w0 + 62 decode without a miss
+__device__ __forceinline__ int window_offset(float mean) {
+    float m = mean == mean ? mean : 0.0f;
+    m = fminf(fmaxf(m, 0.0f), 255.0f);
+    const int w = (int)floorf(m) - 31;
+    return w < 0 ? 0 : (w > kWinMaxOffset ? kWinMaxOffset : w);
+}
+
+__host__ __device__ __forceinline__ bool window_miss(unsigned xw, unsigned w0) {   // xw: rank inside the window, 0 .. 63
+    return (xw == 0u && w0 != 0u) || (xw == (unsigned)kWinTop && w0 != (unsigned)kWinMaxOffset);
+}
+// would the symbol x of a FULL row have been a miss of the window at w0 (statistics of chunks decoded from full rows)
+__host__ __device__ __forceinline__ bool window_would_miss(unsigned x, unsigned w0) {
+    return !(x - w0 - 1u <= 61u) && !(x == 0u && w0 == 0u) && !(x == 255u && w0 == (unsigned)kWinMaxOffset);
+}
+
 }  // namespace l3c
 #endif

@@ -21,69 +21,16 @@
 
 namespace {
 
-constexpr float kLogScalesMin = -7.0f;
-
 using l3c::sigmoid_f;
-using l3c::sigmoid_sat;   // csrc/dmll_core.h
-
-// Accessor concept: float operator()(int ch) -- channel `ch` (0..Kp-1) of the current pixel.
-
-struct MixStats {
-    float max_logit, denom;
-};
-
-template <class Get>
-__device__ __forceinline__ MixStats mix_stats(Get get, int C, int K, int c) {
-    MixStats s;
-    s.max_logit = get(c * K);
-    for (int k = 1; k < K; ++k) s.max_logit = fmaxf(s.max_logit, get(c * K + k));
-    s.denom = 0.0f;
-    for (int k = 0; k < K; ++k) s.denom = s.denom + expf(get(c * K + k) - s.max_logit);
-    return s;
-}
-
-struct MixComponent {
-    float pi, mu, log_sigma;
-};
-
-// x0, x1: actual values of the previously coded channels (RGB scale only, c > 0).
-// e_k = expf(logit_k - max): the softmax numerator.  Callers that have just computed it for the denominator pass it in (the
-// same operation on the same operands: the same bits) instead of paying a second expf.
-template <class Get>
-__device__ __forceinline__ MixComponent mix_component_e(Get get, const MixStats &st, float e_k, int C, int K, int rgb, int c, int k,
-                                                        float x0, float x1);
-
-template <class Get>
-__device__ __forceinline__ MixComponent mix_component(Get get, const MixStats &st, int C, int K, int rgb, int c, int k,
-                                                      float x0, float x1) {
-    return mix_component_e(get, st, expf(get(c * K + k) - st.max_logit), C, K, rgb, c, k, x0, x1);
-}
-
-template <class Get>
-__device__ __forceinline__ MixComponent mix_component_e(Get get, const MixStats &st, float e_k, int C, int K, int rgb, int c, int k,
-                                                        float x0, float x1) {
-    const int CK = C * K;
-    MixComponent m;
-    m.pi = e_k / st.denom;
-    m.mu = get(CK + c * K + k);
-    m.log_sigma = fmaxf(get(2 * CK + c * K + k), kLogScalesMin);
-    if (rgb && c == 1) {
-        m.mu = m.mu + sigmoid_f(get(3 * CK + k)) * x0;
-    } else if (rgb && c == 2) {
-        const float a = sigmoid_f(get(3 * CK + K + k)) * x0;
-        const float b = sigmoid_f(get(3 * CK + 2 * K + k)) * x1;
-        m.mu = m.mu + (a + b);
-    }
-    return m;
-}
-
-__device__ __forceinline__ float cdf_term(float pi, float mu, float inv_sigma, float target) {
-    return pi * sigmoid_sat((target - mu) * inv_sigma);
-}
-
-__device__ __forceinline__ uint32_t cdf_quantise(float cdf, float scale, int l) {
-    return (uint32_t)((int)rintf(cdf * scale) + l) & 0xFFFFu;
-}
+using l3c::sigmoid_sat;   // csrc/dmll_core.h, with the mixture functions below
+using l3c::kLogScalesMin;
+using l3c::MixStats;
+using l3c::MixComponent;
+using l3c::mix_stats;
+using l3c::mix_component;
+using l3c::mix_component_e;
+using l3c::cdf_term;
+using l3c::cdf_quantise;
 
 // ---- per-channel parameters (CDFOut) ---------------------------------------------------------------------------------
 
@@ -167,13 +114,21 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const float *__restrict_
 // chunk-pipelined RGB decode (R, G and B of an image are decoded a chunk apart, each chunk's table built just in time from
 // the symbols the previous channel has produced).  Same device functions, same operation order as the two-kernel path and
 // as encode_intervals_kernel: identical entries.
+// win_stats (round 5; nullptr: the classic form above): per image the miss count its decoder reported two chunks earlier.  The rows of image
+// b then are WINDOW rows (csrc/dmll_core.h: 65 entries around the mixture's mean, a quarter of the sigmoids and of the bytes) when
+// use_window(win_stats[b], range_len) says so -- the decoder evaluates the same function of the same number -- and full rows otherwise,
+// whose entry Lp - 1 (never read by any coder: the top symbol's upper bound is 2^16) then carries the window offset, so that a decoder
+// working on full rows can still count what a window would have missed.  Either way image b's rows start at its full-size slot
+// cdf + b * range_len * Lp.
 __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
                                                                int rgb, int c, int64_t range0, int64_t range_len, int Lp,
-                                                               uint16_t *__restrict__ cdf, int32_t *__restrict__ not_monotone) {
+                                                               uint16_t *__restrict__ cdf, int32_t *__restrict__ not_monotone,
+                                                               const int32_t *__restrict__ win_stats) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kTablePix][Kp + 1]
     __shared__ float s_pi[kTablePix][kMaxK], s_mu[kTablePix][kMaxK], s_inv[kTablePix][kMaxK];
     __shared__ float s_max[kTablePix], s_den[kTablePix];
+    __shared__ int s_w0[kTablePix];
     __shared__ float s_t[260];
     const int Kp = (rgb ? 4 : 3) * C * K;
     const int ld = Kp + 1;
@@ -182,6 +137,7 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
     const int64_t pix0 = range0 + off;
     const int npix = (int)((range_len - off) < kTablePix ? (range_len - off) : kTablePix);
     const int tid = threadIdx.x;
+    const bool window = win_stats && l3c::use_window(win_stats[b], range_len);   // uniform over the image's blocks
     const float *src = P + (b * HW + pix0) * Kp;
     for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];
     for (int i = tid; i < Lp; i += 256) s_t[i] = targets[i];
@@ -213,27 +169,49 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
         }
     }
     __syncthreads();
+    if (win_stats) {   // the window's offset per pixel: around the mixture's mean
+        if (tid < npix) {
+            float mean = 0.0f;
+            for (int k = 0; k < K; ++k) mean = mean + s_pi[tid][k] * s_mu[tid][k];
+            s_w0[tid] = l3c::window_offset(mean);
+        }
+        __syncthreads();
+    }
     const float scale = (float)(65536 - (Lp - 1));
-    const int count = npix * Lp;
-    uint16_t *out = cdf + (b * range_len + off) * Lp;
+    const int Lr = window ? l3c::kWinLp : Lp;        // entries of a row as stored
+    const int count = npix * Lr;
+    uint16_t *out = cdf + b * range_len * Lp + off * Lr;
     const bool aligned4 = ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
     // The strict-monotonicity check the decoder needs (l3c_cdf_check_monotone: entries 0 .. Lp-2 of every row) is done on the
     // entries while they are in registers instead of re-reading the table (a 24 GB pass per batch of 128 otherwise): a thread
     // holds entries e, e + 1; entry e + 2 is the next lane's first; what a wavefront's last lane needs comes from another
-    // wavefront or the next turn of this loop and goes through s_edge, checked after the loop.
+    // wavefront or the next turn of this loop and goes through s_edge, checked after the loop.  (Window rows: entries 0 .. 63.)
     __shared__ uint32_t s_edge[kTablePix * 260 / 128 + 2][2];   // per run of 128 entries: its first and its last entry
     const int lane = tid & 63;
+    const int l_last = window ? l3c::kWinTop - 1 : Lp - 3;   // pairs (l, l + 1) checked for 0 <= l <= l_last
     bool bad = false;
     for (int e = tid * 2; e < count; e += 512) {
         uint32_t v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ee = e + h < count ? e + h : e;
-            const int p = ee / Lp, l = ee - p * Lp;
-            const float t = s_t[l];
-            float acc = 0.0f;
-            for (int k = 0; k < K; ++k) acc = acc + cdf_term(s_pi[p][k], s_mu[p][k], s_inv[p][k], t);
-            v[h] = cdf_quantise(acc, scale, l);
+            const int p = ee / Lr, lr = ee - p * Lr;
+            int l = lr;                       // index into the full row
+            bool plain = true;
+            if (window) {
+                l = s_w0[p] + lr;
+                plain = lr != l3c::kWinLp - 1;
+            } else if (win_stats && lr == Lp - 1) {
+                plain = false;
+            }
+            if (plain) {
+                const float t = s_t[l];
+                float acc = 0.0f;
+                for (int k = 0; k < K; ++k) acc = acc + cdf_term(s_pi[p][k], s_mu[p][k], s_inv[p][k], t);
+                v[h] = cdf_quantise(acc, scale, l);
+            } else {
+                v[h] = (uint32_t)s_w0[p];     // e[64] of a window row / e[Lp - 1] of a full row: the window's offset
+            }
         }
         if (aligned4 && e + 1 < count) {
             *reinterpret_cast<uint32_t *>(out + e) = v[0] | (v[1] << 16);
@@ -241,12 +219,12 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
             out[e] = (uint16_t)v[0];
             if (e + 1 < count) out[e + 1] = (uint16_t)v[1];
         }
-        if (not_monotone) {   // pairs (m, m + 1) with m <= Lp - 3 inside a row: entry index mod Lp
-            const int l0 = e % Lp;
-            bad = bad || (e + 1 < count && l0 <= Lp - 3 && !(v[0] < v[1]));
+        if (not_monotone) {   // pairs (m, m + 1) inside a row: entry index mod Lr
+            const int l0 = e % Lr;
+            bad = bad || (e + 1 < count && l0 <= l_last && !(v[0] < v[1]));
             const uint32_t next = (uint32_t)__shfl_down((int)v[0], 1, 64);   // entry e + 2 (lanes 0 .. 62)
-            const int l1 = l0 + 1 < Lp ? l0 + 1 : 0;
-            bad = bad || (lane < 63 && e + 2 < count && l1 <= Lp - 3 && !(v[1] < next));
+            const int l1 = l0 + 1 < Lr ? l0 + 1 : 0;
+            bad = bad || (lane < 63 && e + 2 < count && l1 <= l_last && !(v[1] < next));
             if (lane == 0) s_edge[e >> 7][0] = v[0];
             if (lane == 63) s_edge[e >> 7][1] = v[1];
         }
@@ -255,8 +233,8 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
         __syncthreads();
         const int runs = (count + 127) >> 7;   // run j: entries 128 j .. 128 j + 127; its last entry against the next run's first
         for (int j = tid; j + 1 < runs; j += 256) {
-            const int m = (128 * j + 127) % Lp;
-            bad = bad || (m <= Lp - 3 && !(s_edge[j][1] < s_edge[j + 1][0]));
+            const int m = (128 * j + 127) % Lr;
+            bad = bad || (m <= l_last && !(s_edge[j][1] < s_edge[j + 1][0]));
         }
         if (__any(bad) && lane == 0) atomicOr(not_monotone, 1);
     }
@@ -478,7 +456,8 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
 }
 
 int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
-                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, l3c_stream_t stream) {
+                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, const int32_t *window_stats,
+                       l3c_stream_t stream) {
     L3C_REQUIRE(P && targets && cdf, "null pointer");
     L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && c >= 0 && c < C, "bad shape");
     L3C_REQUIRE(pix0 >= 0 && npix > 0 && pix0 + npix <= HW, "pixel range outside the image");
@@ -486,12 +465,13 @@ int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets,
     L3C_REQUIRE(Lp >= 2 && Lp <= 260, "Lp out of range (2..260)");
     L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
     L3C_REQUIRE(!(rgb && c > 0) || sym, "the RGB scale needs the symbols of the channels decoded so far");
+    L3C_REQUIRE(!window_stats || Lp == 257, "window rows are defined for the 256-symbol alphabet (Lp == 257)");
     const int Kp = (rgb ? 4 : 3) * C * K;
     const size_t lds = (size_t)kTablePix * (Kp + 1) * sizeof(float);
     L3C_REQUIRE(lds <= 48 * 1024, "Kp too large for the LDS tile");
     const dim3 grid((unsigned)((npix + kTablePix - 1) / kTablePix), (unsigned)B);
     hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, c,
-                       pix0, npix, Lp, cdf, not_monotone);
+                       pix0, npix, Lp, cdf, not_monotone, window_stats);
     int rc = l3c::check_launch("cdf_table_from_P_kernel");
     return rc;   // (the kernel has checked the rows while it held them: not_monotone)
 }

@@ -354,15 +354,19 @@ def cdf_table_mixture(targets, pi, mu, log_sigma, check_monotone=True):
     return cdf, flag
 
 
-def dmll_cdf_table(P_nhwc, sym, targets, C, K, rgb, c, pix0, npix, flag=None):
+def dmll_cdf_table(P_nhwc, sym, targets, C, K, rgb, c, pix0, npix, flag=None, window_stats=None):
     """Fused decoder head: uint16 table rows (viewed as int16, (B, npix, Lp)) of channel c for pixels [pix0, pix0 + npix) of
-    every image; `flag` (int32[1], device) is set if a row is not strictly increasing (never cleared)."""
+    every image; `flag` (int32[1], device) is set if a row is not strictly increasing (never cleared).
+    window_stats (int32 (B,), device; RGB scale only): per image the miss count its decoder reported two chunks earlier -- an image
+    whose count allows it gets 65-entry WINDOW rows packed from the start of its (B, npix, Lp) slot, the others full rows
+    (include/l3c_hip.h, l3c_ac_decode_part); pass the same tensor to `ac_decode_part(window=...)`."""
     B, H, W, _ = P_nhwc.shape
     Lp = targets.shape[0]
     cdf = torch.empty(B, npix, Lp, dtype=torch.int16, device=P_nhwc.device)
     call('l3c_dmll_cdf_table', ptr(P_nhwc, torch.float32), ptr(sym, torch.int16) if sym is not None else None,
          ptr(targets, torch.float32), B, H * W, C, K, int(rgb), c, pix0, npix, Lp, ptr(cdf),
-         ptr(flag, torch.int32) if flag is not None else None, stream())
+         ptr(flag, torch.int32) if flag is not None else None,
+         ptr(window_stats, torch.int32) if window_stats is not None else None, stream())
     return cdf
 
 
@@ -467,18 +471,30 @@ def ac_decode_state(n_streams, device='cuda'):
 
 
 def ac_decode_part(cdf, payload_buf, offsets, nbytes, n_streams, n_sym, flag, state_in, state_out, final, sym_out,
-                   sym_stride, sym_offset):
+                   sym_stride, sym_offset, window=None):
     """One part of `ac_decode_chunks`: decode symbols [sym_offset, sym_offset + n_sym) of every stream from the table rows of
     that range (cdf: (n_streams * n_sym, Lp)), resuming from `state_in` (None: start of the streams) and saving into
     `state_out`; writes into `sym_out` (int16, row stride `sym_stride`).  `flag`: device int32 'table not validated'
-    (None: treat as not validated).  The tuple keeps the tensors alive until the launch."""
+    (None: treat as not validated).  The tuple keeps the tensors alive until the launch.
+    window: None, or (stats_in, stats_out, P_nhwc, sym_all, targets, pix0, C, K, c) for a table built with `dmll_cdf_table(...,
+    window_stats=stats_in)`: streams whose rows are window rows are decoded from those, a symbol outside its window from the pixel's
+    full row evaluated by the decoder itself (needs P, the decoded channels `sym_all` (B, C, H, W) and the bin edges); stats_out
+    (int32 (B,)) receives every stream's miss count of this chunk."""
     part = _lib.AcDecodePart(ptr(cdf), cdf.shape[-1], ptr(payload_buf, torch.uint8), ptr(offsets, torch.int64),
                              ptr(nbytes, torch.int32), n_streams, n_sym,
                              ptr(flag, torch.int32) if flag is not None else None,
                              ptr(state_in) if state_in is not None else None,
                              ptr(state_out) if state_out is not None else None, int(bool(final)),
                              ptr(sym_out, torch.int16), sym_stride, sym_offset)
-    return part, (cdf, payload_buf, offsets, nbytes, flag, state_in, state_out, sym_out)
+    keep = (cdf, payload_buf, offsets, nbytes, flag, state_in, state_out, sym_out)
+    if window is not None:
+        stats_in, stats_out, P_nhwc, sym_all, targets, pix0, C, K, c = window
+        part.window_stats_in, part.window_stats_out = ptr(stats_in, torch.int32), ptr(stats_out, torch.int32)
+        part.P, part.sym_all, part.targets = ptr(P_nhwc, torch.float32), ptr(sym_all, torch.int16), ptr(targets, torch.float32)
+        part.HW, part.pix0 = P_nhwc.shape[1] * P_nhwc.shape[2], pix0
+        part.C, part.K, part.c = C, K, c
+        keep += (stats_in, stats_out, P_nhwc, sym_all, targets)
+    return part, keep
 
 
 def ac_decode_chunks(parts):
