@@ -136,11 +136,12 @@ int l3c_ac_decode(const uint16_t *cdf, int64_t row_stride, int Lp, const uint8_t
  *   sym_out            stream s writes sym_out[s * sym_stride + sym_offset + i], i < n_sym
  * WINDOW ROWS (ABI version 3; all fields NULL / 0: classic rows).  With window_stats_in set, `cdf` was built by l3c_dmll_cdf_table
  * with the same window_stats array: stream s's rows -- at its full-size slot cdf + s * n_sym * Lp -- are 65-entry WINDOW rows around
- * the mixture's mean when window_stats_in[s] says the stream missed at most 1/64 of the symbols two chunks earlier (a quarter of the
- * table arithmetic and bytes of the 257-entry rows), and full rows otherwise.  A symbol outside its window makes the decoder wavefront
+ * the mixture's mean when window_stats_in[s] says the stream missed at most 1/64 of the symbols two chunks earlier (0 <= value < 2^30; a
+ * quarter of the table arithmetic and bytes of the 257-entry rows), and full rows otherwise.  A symbol outside its window makes the decoder wavefront
  * evaluate the full row of that pixel itself from P / sym_all / targets (the table kernel's device functions: the same bits), so
  * the decoded symbols never depend on the row form.  window_stats_out[s] receives the stream's miss count of THIS chunk (what a window
- * would have missed when the rows were full; INT32_MAX when the stream went through the generic pass): feed it to the table call and the
+ * would have missed when the rows were full), bit 30 set when that is more than 1/64 of the chunk's symbols (INT32_MAX when the stream went
+ * through the generic pass): feed it to the table call and the
  * decode part of the chunk after the next one.  RGB scale only (Lp == 257, C == 3), one stream per image: stream s = image s of P.
  *   P, sym_all, targets, HW, C, K, c   as for l3c_dmll_cdf_table;   pix0   first pixel of this chunk (sym_all index of symbol 0)
  */
@@ -199,7 +200,7 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
  *   cdf [B][npix][Lp];  not_monotone: optional flag, set (never cleared) if a row is not strictly increasing
  *   window_stats (ABI version 3; NULL: every row a full row): int32 [B], see l3c_ac_decode_part -- image b's rows are 65-entry
  *   window rows (entries 0..63 = cdf[w0 .. w0 + 63], entry 64 = the window's offset w0) packed from the start of its full-size slot
- *   cdf + b * npix * Lp when window_stats[b] >= 0 and 64 * window_stats[b] <= npix; otherwise full rows whose (never read) entry Lp - 1
+ *   cdf + b * npix * Lp when 0 <= window_stats[b] < 2^30; otherwise full rows whose (never read) entry Lp - 1
  *   carries w0.  Lp must be 257.
  */
 int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,

@@ -549,7 +549,10 @@ class Bitcoding(object):
             ops.ac_decode_chunks(parts[k:k + 8])
         return sym
 
-    RGB_CHUNKS = 16          # chunks per RGB channel for batches of 16 images and more
+    RGB_PROBE = 1024         # symbols of the two probe chunks a channel starts with when window rows are in use (a multiple of 64)
+    RGB_CHUNKS = 32          # chunks per RGB channel for batches of 16 images and more (round 5, with window rows: 32 instead of 16 --
+    #                          the row form of a chunk follows the stream's misses two chunks earlier, and shorter chunks follow faster:
+    #                          batch of 128 0.379 -> 0.365 s, the default-init checkpoint 0.585 -> 0.55 s)
     RGB_CHUNKS_FEW = 32      # ... for a few images: the pipeline's fill (two extra chunk steps) weighs more than a step's launches
 
     def _decode_rgb_pipelined(self, P, targets, payloads, B, C, K, H, W):
@@ -573,6 +576,11 @@ class Bitcoding(object):
         step = -(-HW // n_chunks)
         step = -(-step // 64) * 64                       # chunk boundaries on the 64-symbol store blocks
         bounds = [(p0, min(step, HW - p0)) for p0 in range(0, HW, step)]
+        if self.rgb_window == 'auto' and HW >= 16 * self.RGB_PROBE:
+            # window rows (below) start from what the stream's decoder saw two chunks earlier: the first two chunks are short PROBES on
+            # full rows (their tables cost 4x a window chunk's per pixel), the regular chunks follow
+            P2 = 2 * self.RGB_PROBE
+            bounds = [(0, self.RGB_PROBE), (self.RGB_PROBE, self.RGB_PROBE)] + [(p0, min(step, HW - p0)) for p0 in range(P2, HW, step)]
         sym = torch.zeros(B, C, H, W, dtype=torch.int16, device='cuda')
         packed = [ops.pack_streams(payloads[c::C]) for c in range(C)]
         # flags[c] is only ever SET (never cleared) by the table kernels.  With the overlapped schedule the table kernel of
@@ -584,9 +592,10 @@ class Bitcoding(object):
         # WINDOW ROWS (round 5; include/l3c_hip.h, l3c_ac_decode_part).  A full row has 257 entries although the symbol almost always
         # lies near the mixture's mean: chunk j of a channel gets 65-entry rows around the mean for every image whose decoder missed at most
         # 1/64 of the symbols of chunk j - 2 (the newest chunk that is certain to be complete when the tables of chunk j are built, with either
-        # schedule below), full rows otherwise and for chunks 0 and 1 -- a quarter of the table arithmetic and bytes, the symbols the
-        # same (a decoder evaluates a missed pixel's full row itself).  stats[c][j + 2] is written by chunk j's decoders, read (slot j)
-        # by chunk j's table kernel and decoders alike; -1 = unknown = full rows.  rgb_window = 'always' / 'never' (tests) force a form.
+        # schedule below), full rows otherwise and for chunks 0 and 1 (the probes) -- a quarter of the table arithmetic and bytes, the
+        # symbols the same (a decoder evaluates a missed pixel's full row itself).  stats[c][j + 2] is written by chunk j's decoders (its miss
+        # count, bit 30 set when above 1/64 of the chunk), read (slot j) by chunk j's table kernel and decoders alike; -1 = unknown = full
+        # rows.  rgb_window = 'always' / 'never' (tests) force a form.
         n_ch = len(bounds)
         if self.rgb_window == 'auto':
             stats = torch.full((C, n_ch + 2, B), -1, dtype=torch.int32, device='cuda')

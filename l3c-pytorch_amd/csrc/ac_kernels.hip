@@ -776,9 +776,11 @@ struct WindowCtx {
     int C, K, c;
 };
 
+// (no "memory" clobber: behind one the compiler re-reads everything it holds from memory -- the kernel arguments among it -- once per
+// ring block; the ring's contents are ordered by the volatile DMA waits, which volatile asm statements are never moved across)
 __device__ __forceinline__ uint32_t lds_read_u16_now(uint32_t addr) {
     uint32_t v;
-    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+    asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr));
     return v;
 }
 
@@ -852,20 +854,17 @@ struct DecodeArgsPack {
 // WINDOW: the instantiation for the streams whose rows of this chunk are window rows (NJ == 1): every symbol is ranked inside its window;
 // a miss -- and, when the table is not validated, EVERY symbol -- goes through the pixel's full row, evaluated here, with the reference's
 // literal arithmetic (decode_symbol<4>), so that this pass decodes what the classic generic pass decodes from full rows.
-template <int NJ, int IPB_ = (NJ == 1 ? 3 : 9), bool WINDOW = false>
-__global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack pack) {
+template <int NJ, int IPB_, bool WINDOW>
+__device__ __forceinline__ void ring_decode_body(const DecodeArgs &a, uint8_t *ring) {
     static_assert(!WINDOW || NJ == 1, "window rows fill one row register");
     using C = RingCfg<NJ, IPB_>;
-    const DecodeArgs &a = pack.part[blockIdx.y];
-    if ((int64_t)blockIdx.x >= a.n_streams) return;
     const uint16_t *cdf = a.cdf;
     const int64_t table_bytes = a.table_bytes;
     const uint32_t n_sym = a.n_sym;
     const bool has_win = a.win.stats_in != nullptr;
-    if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x], (long long)n_sym))) return;   // not this kernel's kind of stream
+    if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x]))) return;   // not this kernel's kind of stream
     const int Lp = WINDOW ? l3c::kWinLp : a.Lp;
     const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
-    __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
     const int top = Lp - 2;
@@ -970,6 +969,26 @@ __global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack
     if (a.state_out && lane == 0) a.state_out[s] = DecodeState{low, high, value, src.pos, {0u, 0u, 0u, 0u}};
     // a stream that needed this pass reports no usable statistics: the chunk after the next one gets full rows
     if (has_win && a.win.stats_out && lane == 0) a.win.stats_out[s] = 0x7FFFFFFF;
+}
+
+// WITH_WINDOW: the launch may hold streams on window rows (RGB parts of a windowed decode): such a block runs the <1, 3, WINDOW> body, the
+// others the classic one -- in ONE kernel, so that the two kinds of streams of a pipeline step run side by side (as two launches on one HIP
+// stream they would run one after the other: the chains are latency-bound, the step would take the SUM of its slowest window stream and
+// its slowest full-row stream).
+template <int NJ, int IPB_ = (NJ == 1 ? 3 : 9), bool WITH_WINDOW = false>
+__global__ __launch_bounds__(64) void ac_decode_ring_kernel(const DecodeArgsPack pack) {
+    using C = RingCfg<NJ, IPB_>;
+    static_assert(!WITH_WINDOW || (NJ == 4 && IPB_ >= 3), "the window body's ring (4 x 3 KB) must fit the classic one");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
+    const DecodeArgs &a = pack.part[blockIdx.y];
+    if ((int64_t)blockIdx.x >= a.n_streams) return;
+    if constexpr (WITH_WINDOW) {
+        if (a.win.stats_in != nullptr && l3c::use_window(a.win.stats_in[blockIdx.x])) {
+            ring_decode_body<1, 3, true>(a, ring);
+            return;
+        }
+    }
+    ring_decode_body<NJ, IPB_, false>(a, ring);
 }
 
 // ---- the lean fast decoder (round 4) --------------------------------------------------------------------------------------
@@ -1084,13 +1103,54 @@ __device__ __forceinline__ void lean_symbol_body(const RowHi<NJ> &row, const Val
         }
     }
 }
+// The mixture of pixel n of image b, one component per lane (lane k < K: pi_k, mu_k, 1 / sigma_k; the softmax's denominator is the
+// SEQUENTIAL sum of the numerators, gathered lane by lane), and from it the 64 entries cdf[wbase + lane] as a window row of the lean
+// decoder (entries in the high half-words): what the table kernel would have written for a window at offset wbase.
+struct LaneMixture {
+    float pi, mu, inv;
+};
+__device__ __forceinline__ LaneMixture window_lane_mixture(const WindowCtx &w, int64_t b, int64_t n, int lane) {
+    const int C = w.C, K = w.K, c = w.c;
+    const float *px = w.P + (b * w.HW + n) * (int64_t)(4 * C * K);
+    auto get = [&](int ch) { return px[ch]; };
+    float x0 = 0.f, x1 = 0.f;
+    if (c > 0) {
+        x0 = (float)w.sym[(b * C + 0) * w.HW + n];
+        if (c > 1) x1 = (float)w.sym[(b * C + 1) * w.HW + n];
+    }
+    const int k = lane < K ? lane : K - 1;
+    l3c::MixStats st;
+    st.max_logit = get(c * K);
+    for (int j = 1; j < K; ++j) st.max_logit = fmaxf(st.max_logit, get(c * K + j));
+    const float e_k = expf(get(c * K + k) - st.max_logit);
+    st.denom = 0.0f;
+    for (int j = 0; j < K; ++j) st.denom = st.denom + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e_k), j));
+    const l3c::MixComponent m = l3c::mix_component_e(get, st, e_k, C, K, 1, c, k, x0, x1);
+    return LaneMixture{m.pi, m.mu, expf(-m.log_sigma)};
+}
+__device__ __forceinline__ RowHi<1> window_row_at(const WindowCtx &w, const LaneMixture &mx, int wbase, int lane, bool &monotone) {
+    const float t = w.targets[wbase + lane];
+    float acc = 0.0f;
+    for (int j = 0; j < w.K; ++j) {
+        const float pi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx.pi), j));
+        const float mu = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx.mu), j));
+        const float inv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mx.inv), j));
+        acc = acc + l3c::cdf_term(pi, mu, inv, t);
+    }
+    const uint32_t v = l3c::cdf_quantise(acc, (float)(65536 - 256), wbase + lane);
+    const uint32_t nxt = (uint32_t)__shfl_down((int)v, 1, 64);
+    monotone = !__any(lane < 63 && !(v < nxt));
+    return RowHi<1>{v << 16};
+}
+
 // A symbol of a WINDOW row (csrc/dmll_core.h; entries 0 .. 63 in the high half-words like every lean row; w0: the window's offset, the
 // row's entry 64, read from the ring by the caller).
 // Ranked inside the window; unless that is a miss, the state advances as for a 64-symbol alphabet whose top symbol is entry 63, and
-// x = w0 + x'.  On a MISS nothing is touched and true is returned: the caller evaluates the pixel's full row (once the prefetched LDS
-// reads have landed) and decodes the symbol from that with lean_symbol<4>.
+// x = w0 + x'.  On a MISS nothing is touched and its direction is returned (-1: the symbol lies below the window, +1: above; 0: decoded):
+// the caller then evaluates the 64 entries next to the window on that side (window_row_at, once the prefetched LDS reads have landed) and
+// tries again, until the symbol is inside.
 template <bool FULLRANGE>
-__device__ __forceinline__ bool lean_symbol_window_body(const RowHi<1> &row, uint32_t w0, bool advance, LeanState &st, WaveBits &src, uint32_t &x) {
+__device__ __forceinline__ int lean_symbol_window_body(const RowHi<1> &row, uint32_t w0, bool advance, LeanState &st, WaveBits &src, uint32_t &x) {
     const uint32_t d = (uint32_t)(st.vb >> 32) - st.low;
     RowHi<1> t;
     if (FULLRANGE) t = row;
@@ -1099,7 +1159,7 @@ __device__ __forceinline__ bool lean_symbol_window_body(const RowHi<1> &row, uin
     uint32_t x1 = rank > 1u ? rank : 1u;
     asm("" : "+s"(x1));
     const uint32_t xw = x1 - 1u;
-    if (l3c::window_miss(xw, w0) && d <= st.range) return true;   // (a value outside [low, high] is not a miss: it marks the stream below)
+    if (l3c::window_miss(xw, w0) && d <= st.range) return xw == 0u ? -1 : 1;   // (a value outside [low, high] is not a miss: it marks the stream below)
     st.bad |= d > st.range ? 1u : 0u;
     uint32_t t_lo, t_hi;
     row_fetch2(t, xw, x1, t_lo, t_hi);
@@ -1116,9 +1176,9 @@ __device__ __forceinline__ bool lean_symbol_window_body(const RowHi<1> &row, uin
             st.nbits += 32u;
         }
     }
-    return false;
+    return 0;
 }
-__device__ __forceinline__ bool lean_symbol_window(const RowHi<1> &row, uint32_t w0, bool advance, LeanState &st, WaveBits &src, uint32_t &x) {
+__device__ __forceinline__ int lean_symbol_window(const RowHi<1> &row, uint32_t w0, bool advance, LeanState &st, WaveBits &src, uint32_t &x) {
     if (__builtin_expect(st.range == 0xFFFFFFFFu, 0)) return lean_symbol_window_body<true>(row, w0, advance, st, src, x);
     return lean_symbol_window_body<false>(row, w0, advance, st, src, x);
 }
@@ -1233,6 +1293,72 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
     [r3] "=&s"(r3), [x] "=&s"(x), [x1] "=&s"(x1), [lo] "=&s"(lo), [hi] "=&s"(hi), [w] "=&s"(w), [c] "=&s"(c), [a2] "=&v"(a2)
 #define L3C_BLOCK_CLOBBERS "s94", "s95", "s96", "s97", "s98", "s99", "s100", "s101", "m0", "scc", "vcc", "memory"
 
+// WINDOW rows: the same symbol, plus the test for a MISS right behind the rank (csrc/dmll_core.h).  The rank sits at an edge of the window
+// iff x1 = x' + 1 is 1 or 64, i.e. (x1 & 62) == 0: ONE s_and and a branch that is not taken (4.2 ns) on the common path.  At an edge the
+// out-of-line handler decides with the row's window offset -- entry 64 of the row, read one symbol ahead by lane 0 (ds_read_u16 at the
+// lane address + 128) and handed to the scalar unit at the start of the symbol --: x' = 0 is exact iff w0 == 0, x' = 63 iff w0 == 192
+// (then back into the symbol); otherwise the loop is LEFT before the symbol has touched the state, with `hit` = 1 / 2 (first / second row
+// of the pair), the prefetched row landed, `j` at the pair.  The caller decodes the missed symbol from the pixel's full row, finishes the
+// pair with the compiled symbol and comes back for the rest of the block.
+#define L3C_SYMBOL_RANK1W(SET_M0_TO_ROW, EDGE, BACK)                                                               \
+    "s_and_b64 %[m0], %[m0], %[valid]\n\t"                                                                          \
+    "s_bcnt1_i32_b64 %[r0], %[m0]\n\t"                                                                              \
+    "s_max_u32 %[x1], %[r0], 1\n\ts_add_i32 %[x], %[x1], -1\n\t"                                                    \
+    "s_and_b32 %[t0], %[x1], 62\n\t"                                                                                \
+    "s_cbranch_scc0 " EDGE "\n"                                                                                     \
+    BACK ":\n\t"                                                                                                    \
+    SET_M0_TO_ROW "\n\t"                                                                                            \
+    "v_readlane_b32 %[lo], v96, %[x]\n\tv_readlane_b32 %[hi], v96, %[x1]\n\t"
+#define L3C_SYMBOL1W(R0, PREFETCH, SET_M0_TO_ROW, BETWEEN, EDGE, BACK) \
+    L3C_SYMBOL_SCALE1(R0) PREFETCH L3C_SYMBOL_RANK1W(SET_M0_TO_ROW, EDGE, BACK) L3C_SYMBOL_ADVANCE(BETWEEN)
+// x' at an edge: t0 = w0 (low edge) or 192 - w0 (high edge); 0 -> the symbol is exact, back; else leave with hit = N
+#define L3C_EDGE_HANDLER(LABEL, BACK, N)                                                                           \
+    LABEL ":\n\t"                                                                                                   \
+    "s_sub_u32 %[t0], 192, %[wv]\n\t"                                                                               \
+    "s_cmp_eq_u32 %[x1], 1\n\ts_cselect_b32 %[t0], %[wv], %[t0]\n\t"                                                \
+    "s_cmp_eq_u32 %[t0], 0\n\ts_cbranch_scc1 " BACK "\n\t"                                                          \
+    "s_mov_b32 %[hit], " N "\n\ts_waitcnt lgkmcnt(0)\n\ts_branch 9f\n"
+
+__device__ __forceinline__ void lean_block_uniform(LeanState &st, uint32_t &wrel, uint32_t &minspan, uint32_t value);
+
+// rows j0 (even; set A holds it, wA lane 0 its entry 64) .. R - 1 of a block of window rows; returns with hit != 0 and j at the pair of
+// the missed row, or hit == 0 and j == R
+__device__ __forceinline__ void lean_block_asm_window(RowHi<1> &A, RowHi<1> &B, uint32_t &wA, const ValidLanes<1> &valid, LeanState &st,
+                                                      uint32_t &wrel, uint32_t &minspan, uint32_t window, int &kept, uint32_t &addr_next,
+                                                      uint32_t addr_cross, uint32_t row_bytes, uint32_t R, uint32_t top, uint32_t &j,
+                                                      uint32_t &hit) {
+    uint64_t m0;
+    uint32_t span, d, t0, r0, r1, r2, r3, x, x1, lo, hi, w, c, a2, wv, wB = 0;
+    uint32_t value = (uint32_t)(st.vb >> 32);
+    asm volatile(
+        "s_mov_b32 s97, %[value]\n\ts_mov_b64 s[98:99], %[buf]\n\ts_mov_b32 s101, 0\n"
+        "1:\n\t"
+        "v_readfirstlane_b32 %[wv], %[wA]\n\t"
+        L3C_SYMBOL1W("%[a0]", L3C_ROW_READ1("%[b0]", "%[addr]") "ds_read_u16 %[wB], %[addr] offset:128\n\tv_add_u32 %[addr], %[rowb], %[addr]\n\t",
+                     "s_mov_b32 m0, %[j]", L3C_CROSS_SELECT, "2f", "3")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_readfirstlane_b32 %[wv], %[wB]\n\t"
+        L3C_SYMBOL1W("%[b0]", L3C_ROW_READ1("%[a0]", "%[a2]") "ds_read_u16 %[wA], %[a2] offset:128\n\tv_add_u32 %[addr], %[rowb], %[addr]\n\t",
+                     "s_add_u32 m0, %[j], 1", "s_add_u32 %[j], %[j], 2\n\t", "4f", "5")
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_cmp_lt_u32 %[j], %[R]\n\ts_cbranch_scc1 1b\n\t"
+        "s_branch 9f\n"
+        L3C_EDGE_HANDLER("2", "3b", "1")
+        L3C_EDGE_HANDLER("4", "5b", "2")
+        "9:\n\t"
+        "s_mov_b32 %[value], s97\n\ts_mov_b64 %[buf], s[98:99]"
+        : [a0] "+v"(A.a), [b0] "+v"(B.a), [wA] "+v"(wA), [wB] "+v"(wB), [m0] "=&s"(m0), [wv] "=&s"(wv), [hit] "+s"(hit),
+          [kept] "+v"(kept), [addr] "+v"(addr_next), [low] "+s"(st.low), [nh] "+s"(st.nh), [range] "+s"(st.range),
+          [nbits] "+s"(st.nbits), [wrel] "+s"(wrel), [bad] "+s"(st.bad), [minspan] "+s"(minspan), [j] "+s"(j), [value] "+s"(value),
+          [buf] "+s"(st.buf), [span] "=&s"(span), [d] "=&s"(d), [t0] "=&s"(t0), [r0] "=&s"(r0), [r1] "=&s"(r1), [r2] "=&s"(r2),
+          [r3] "=&s"(r3), [x] "=&s"(x), [x1] "=&s"(x1), [lo] "=&s"(lo), [hi] "=&s"(hi), [w] "=&s"(w), [c] "=&s"(c), [a2] "=&v"(a2)
+        : [cur] "v"(window), [across] "v"(addr_cross), [rowb] "s"(row_bytes), [R] "s"(R), [top] "s"(top), [valid] "s"(valid.a)
+        : "v96", L3C_BLOCK_CLOBBERS);
+    lean_block_uniform(st, wrel, minspan, value);
+    j = (uint32_t)__builtin_amdgcn_readfirstlane((int)j);
+    hit = (uint32_t)__builtin_amdgcn_readfirstlane((int)hit);
+}
+
 // what an asm statement returns counts as divergent: say that the state is wave-uniform (it already sits in SGPRs)
 __device__ __forceinline__ void lean_block_uniform(LeanState &st, uint32_t &wrel, uint32_t &minspan, uint32_t value) {
     st.low = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.low);
@@ -1304,20 +1430,19 @@ __device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, const V
 // scales' loop.  The hand-written loop runs a block as if no symbol could miss; afterwards every lane compares ITS row's rank with its
 // row's window offset (one LDS read per block): a real miss in the block -- the first one is always seen, the state before it is
 // valid -- sends the block through the careful symbols below, which evaluate a missed pixel's full row in the wavefront.
-template <int NJ, bool ALLVALID, int IPB_ = (NJ == 1 ? 3 : 9), bool WINDOW = false>
-__global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack pack) {
+template <int NJ, bool ALLVALID, int IPB_, bool WINDOW>
+__device__ __forceinline__ void lean_decode_body(const DecodeArgs &a, uint8_t *ring) {
     static_assert(!WINDOW || (NJ == 1 && ALLVALID), "window rows fill one row register, all 64 lanes hold entries");
     using C = RingCfg<NJ, IPB_>;
-    const DecodeArgs &a = pack.part[blockIdx.y];
-    if ((int64_t)blockIdx.x >= a.n_streams) return;
+    // ([measured, round 5] s_setprio 3 here -- a few hundred latency-bound wavefronts beside the table kernel's thousands -- changes nothing:
+    // 0.415 vs 0.404 s per batch of 128)
     const uint16_t *cdf = a.cdf;
     const int64_t table_bytes = a.table_bytes;
     const uint32_t n_sym = a.n_sym;
     const bool has_win = a.win.stats_in != nullptr;
-    if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x], (long long)n_sym))) return;   // not this kernel's kind of stream
+    if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x]))) return;   // not this kernel's kind of stream
     const int Lp = WINDOW ? l3c::kWinLp : a.Lp;
     const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
-    __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
     const int64_t s = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t top = (uint32_t)(Lp - 2);
@@ -1422,28 +1547,38 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
     else valid = valid_lanes4(lane, (int)top);
     int kept = 0;
     uint32_t misses = 0;   // WINDOW: symbols that fell outside their window; classic rows of a windowed part: symbols a window would have missed
-    bool miss = false;
+    int miss = 0;          // WINDOW: direction of the careful symbol's miss (0: decoded)
+    uint32_t w0_j = 0;     // WINDOW: the window offset of the row the careful symbol works on
+    auto row_w0_addr = [&](uint32_t k, uint32_t j) -> uint32_t { return block_base(k) + j * row_bytes + 2u * (uint32_t)l3c::kWinTop + 2u; };   // entry 64
     // One careful symbol.  WINDOW: a miss leaves the state untouched (L3C_LEAN_FIXUP then decodes the symbol from the pixel's full row,
     // AFTER the wait for the prefetched row: no LDS read is in flight while that long path runs)
 #define L3C_LEAN_SYMBOL(ROW, ADVANCE, J)                                                                                   \
     if constexpr (WINDOW) {  /* (the row's entry 64: its window offset; the read also lands the prefetched row early) */   \
-        const uint32_t w0_j = lds_read_u16_now(block_base(k) + (uint32_t)(J) * row_bytes + 2u * (uint32_t)l3c::kWinTop + 2u); \
-        miss = lean_symbol_window(ROW, (uint32_t)__builtin_amdgcn_readfirstlane((int)w0_j), ADVANCE, st, src, x);           \
+        w0_j = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_read_u16_now(row_w0_addr(k, (uint32_t)(J))));              \
+        miss = lean_symbol_window(ROW, w0_j, ADVANCE, st, src, x);                                                         \
     } else {                                                                                                               \
         lean_symbol<NJ, ALLVALID>(ROW, valid, top, ADVANCE, st, src, x);                                                   \
     }
 #define L3C_LEAN_FIXUP(J, ADVANCE)                                                                                         \
     if constexpr (WINDOW) {                                                                                                \
-        if (__builtin_expect(miss, 0)) {                                                                                   \
-            const Regs<4> full = window_full_row(a.win, s, a.win.pix0 + (int64_t)(i0 + (J)), lane);                        \
-            if (full_row_monotone(full, lane)) {                                                                           \
-                const RowHi<4> fh{full.a << 16, full.b << 16, full.c << 16, full.d << 16};                                 \
-                lean_symbol<4, true>(fh, ValidLanes<4>{~0ull, ~0ull, ~0ull, ~0ull}, 255u, ADVANCE, st, src, x);            \
-            } else {                                                                                                       \
-                st.bad = 1u;   /* a row the fast pass must not rank: the generic pass decodes this chunk */                \
-            }                                                                                                              \
+        if (__builtin_expect(miss != 0, 0)) {                                                                              \
+            /* further windows of the same pixel's row, 62 symbols on in the direction of the miss (so that the symbol next to the old */ \
+            /* window is inside the new one), until the symbol is inside: the direction never turns, the alphabet's ends are exact */ \
+            const LaneMixture lm = window_lane_mixture(a.win, s, a.win.pix0 + (int64_t)(i0 + (J)), lane);                  \
+            int wb = (int)w0_j;                                                                                            \
+            do {                                                                                                           \
+                wb = miss > 0 ? (wb + 62 < l3c::kWinMaxOffset ? wb + 62 : l3c::kWinMaxOffset) : (wb > 62 ? wb - 62 : 0);    \
+                bool mono;                                                                                                 \
+                const RowHi<1> rw = window_row_at(a.win, lm, wb, lane, mono);                                              \
+                if (!mono) {                                                                                               \
+                    st.bad = 1u;   /* a row the fast pass must not rank: the generic pass decodes this chunk */            \
+                    break;                                                                                                 \
+                }                                                                                                          \
+                miss = lean_symbol_window(rw, (uint32_t)wb, ADVANCE, st, src, x);                                          \
+            } while (miss != 0);                                                                                           \
             misses += 1u;                                                                                                  \
         }                                                                                                                  \
+        x -= w0_j;   /* WINDOW: `kept` holds window-relative values (as the hand-written loop leaves them) until the block ends */ \
     }                                                                                                                      \
     kept = lane == (int)(J) ? (int)x : kept;
     for (uint32_t k = 0; k < n_blocks; ++k) {
@@ -1477,19 +1612,58 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
                 }
                 const LeanState saved = st;
                 uint32_t minspan = 0xFFFFFFFFu;
-                lean_block_asm(rowA, rowB, valid, st, wrel, minspan, window, kept, addr_next, addr_cross, row_bytes, R, top);
-                st.widx = src.base + wofs + wrel;
-                done = minspan != 0u && st.bad == 0u;
                 if constexpr (WINDOW) {
-                    // lane j holds the rank x' of row j: a real miss?  (the loop ran on as if not -- everything after the first miss is
-                    // garbage, but the first one is seen: the state before it was valid.)  None: the symbols are w0 + x'.
-                    const uint32_t r_l = (uint32_t)lane < R ? (uint32_t)lane : R - 1u;
-                    const uint32_t w0_l = lds_read_u16_now(block_base(k) + r_l * row_bytes + 2u * (uint32_t)l3c::kWinTop + 2u);   // entry 64
-                    const bool miss_l = (uint32_t)lane < R && l3c::window_miss((uint32_t)kept, w0_l);
-                    done = done && __builtin_amdgcn_ballot_w64(miss_l) == 0ull;
-                    if (done) kept += (int)w0_l;
+                    // rows in pairs through the hand-written loop; it leaves at a MISS (hit = 1 / 2: first / second row of pair j), with the
+                    // state as before that symbol: the pair is finished here -- the missed symbol from the pixel's full row -- and the loop
+                    // re-entered for the rest of the block
+                    uint32_t j = 0u, hit = 0u;
+                    uint32_t addr = addr_next;
+                    done = true;
+                    while (true) {
+                        uint32_t wA = lds_read_u16_now(row_w0_addr(k, j));
+                        hit = 0u;
+                        lean_block_asm_window(rowA, rowB, wA, valid, st, wrel, minspan, window, kept, addr, addr_cross, row_bytes, R, top, j, hit);
+                        st.widx = src.base + wofs + wrel;
+                        if (__builtin_expect(minspan == 0u || st.bad != 0u, 0)) {   // the whole 32-bit range / a bad value: the block again, the careful way
+                            done = false;
+                            break;
+                        }
+                        if (hit == 0u) break;
+                        if (hit == 1u) {   // A: row j (the miss), B: row j + 1 (landed), addr: row j + 2
+                            L3C_LEAN_SYMBOL(rowA, true, j)
+                            L3C_LEAN_FIXUP(j, true)
+                            row_hi_issue(j + 2u == R ? addr_cross : addr, rowA);
+                            addr += row_bytes;
+                            L3C_LEAN_SYMBOL(rowB, true, j + 1u)
+                            row_hi_wait(rowA);
+                            L3C_LEAN_FIXUP(j + 1u, true)
+                        } else {           // B: row j + 1 (the miss), A: row j + 2 (landed), addr: row j + 3
+                            L3C_LEAN_SYMBOL(rowB, true, j + 1u)
+                            L3C_LEAN_FIXUP(j + 1u, true)
+                        }
+                        j += 2u;
+                        if (__builtin_expect(st.bad != 0u, 0)) {
+                            done = false;
+                            break;
+                        }
+                        if (j >= R) break;
+                        // the bit window for the rest of the block (<= R - j words from here), as at the block's start
+                        if (st.widx - src.base >= 64u) src.next_window();
+                        wrel = st.widx - src.base;
+                        wofs = 0u;
+                        window = src.cur;
+                        if (wrel >= 32u) {
+                            window = src.late_window();
+                            wofs = 32u;
+                            wrel -= 32u;
+                        }
+                    }
+                } else {
+                    lean_block_asm(rowA, rowB, valid, st, wrel, minspan, window, kept, addr_next, addr_cross, row_bytes, R, top);
+                    st.widx = src.base + wofs + wrel;
+                    done = minspan != 0u && st.bad == 0u;
                 }
-                if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range, a bad value or a window miss: again, the careful way
+                if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range or a bad value: again, the careful way
                     st = saved;
                     row_hi_issue(block_addr(k), rowA);
                     row_hi_wait(rowA);
@@ -1533,14 +1707,19 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
             if (lane == 0) dst[0] = (int16_t)-1;
             return;
         }
+        if constexpr (WINDOW) {   // `kept` is window-relative on every path: + the row's offset (entry 64 of row `lane`)
+            const uint32_t r_l = (uint32_t)lane < rows ? (uint32_t)lane : rows - 1u;
+            kept += (int)lds_read_u16_now(row_w0_addr(k, r_l));
+        }
         if constexpr (!WINDOW && NJ == 4) {
             // full rows of a windowed part: what would a window have missed?  The (never decoded) entry Lp - 1 of row j carries its offset
             // (l3c_dmll_cdf_table); block k is still in its ring slot
-            if (has_win) {
+            // -- sampled on every fourth block (x 4): an estimate is all the decision needs, and a block here is only 4 .. 16 symbols
+            if (has_win && (k & 3u) == 0u) {
                 const uint32_t r_l = (uint32_t)lane < rows ? (uint32_t)lane : rows - 1u;
                 const uint32_t w0_l = lds_read_u16_now(block_base(k) + r_l * row_bytes + (uint32_t)(Lp - 1) * 2u);
                 const bool m_l = (uint32_t)lane < rows && l3c::window_would_miss((uint32_t)kept & 0xFFFFu, w0_l);
-                misses += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m_l));
+                misses += 4u * (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(m_l));
             }
         }
         if ((uint32_t)lane < rows) dst[i0 + (uint32_t)lane] = (int16_t)kept;
@@ -1549,7 +1728,24 @@ __global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack
 #undef L3C_LEAN_FIXUP
     if (a.state_out && lane == 0)
         a.state_out[s] = DecodeState{st.low, ~st.nh, (uint32_t)(st.vb >> 32), st.widx * 32u - st.nbits, {0u, 0u, 0u, 0u}};
-    if (has_win && a.win.stats_out && lane == 0) a.win.stats_out[s] = (int32_t)(misses < 0x7FFFFFFFu ? misses : 0x7FFFFFFFu);
+    if (has_win && a.win.stats_out && lane == 0) a.win.stats_out[s] = l3c::window_stat(misses, n_sym, WINDOW ? 64u : 128u);
+}
+
+// WITH_WINDOW: see ac_decode_ring_kernel -- window-row streams and full-row streams of a launch side by side in one kernel
+template <int NJ, bool ALLVALID, int IPB_ = (NJ == 1 ? 3 : 9), bool WITH_WINDOW = false>
+__global__ __launch_bounds__(64) void ac_decode_lean_kernel(const DecodeArgsPack pack) {
+    using C = RingCfg<NJ, IPB_>;
+    static_assert(!WITH_WINDOW || (NJ == 4 && ALLVALID && IPB_ >= 3), "window rows: parts of the 256-symbol alphabet; the window body's ring must fit");
+    __shared__ __attribute__((aligned(16))) uint8_t ring[C::NB * C::BLOCK_BYTES + 512];   // + the bit reader's windows
+    const DecodeArgs &a = pack.part[blockIdx.y];
+    if ((int64_t)blockIdx.x >= a.n_streams) return;
+    if constexpr (WITH_WINDOW) {
+        if (a.win.stats_in != nullptr && l3c::use_window(a.win.stats_in[blockIdx.x])) {
+            lean_decode_body<1, true, 3, true>(a, ring);
+            return;
+        }
+    }
+    lean_decode_body<NJ, ALLVALID, IPB_, false>(a, ring);
 }
 
 __global__ __launch_bounds__(256) void check_monotone_kernel(const uint16_t *__restrict__ cdf, int64_t n_rows, int Lp,
@@ -1586,11 +1782,10 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
     if (fast_pass) {   // streams that leave the fast path (or all, if the table is not validated) mark themselves
         bool full = true;   // every part codes the 256-symbol alphabet: all entries of the four row registers are table entries
         for (int i = 0; i < n_parts; ++i) full = full && pack.part[i].Lp == 257;
-        if (any_win) {
-            hipLaunchKernelGGL((ac_decode_lean_kernel<1, true, 3, true>), grid, block, 0, st, pack);
-            const int rcw = l3c::check_launch("ac_decode_lean_kernel<window>");
-            if (rcw != L3C_OK) return rcw;
-        }
+        if (any_win) {   // (l3c_ac_decode_chunks has checked: every windowed part codes the 256-symbol alphabet)
+            if (crowd) hipLaunchKernelGGL((ac_decode_lean_kernel<4, true, 3, true>), grid, block, 0, st, pack);
+            else hipLaunchKernelGGL((ac_decode_lean_kernel<4, true, 9, true>), grid, block, 0, st, pack);
+        } else
         if (small) hipLaunchKernelGGL((ac_decode_lean_kernel<1, false>), grid, block, 0, st, pack);
         else if (crowd && full) hipLaunchKernelGGL((ac_decode_lean_kernel<4, true, 3>), grid, block, 0, st, pack);
         else if (crowd) hipLaunchKernelGGL((ac_decode_lean_kernel<4, false, 3>), grid, block, 0, st, pack);
@@ -1601,11 +1796,9 @@ int launch_ring_decode(DecodeArgsPack pack, int n_parts, bool fast_pass, hipStre
     }
     for (int i = 0; i < n_parts; ++i) pack.part[i].force = fast_pass ? 0 : 1;
     if (any_win) {
-        hipLaunchKernelGGL((ac_decode_ring_kernel<1, 3, true>), grid, block, 0, st, pack);
-        const int rcw = l3c::check_launch("ac_decode_ring_kernel<window>");
-        if (rcw != L3C_OK) return rcw;
-    }
-    if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1>), grid, block, 0, st, pack);
+        if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, 3, true>), grid, block, 0, st, pack);
+        else hipLaunchKernelGGL((ac_decode_ring_kernel<4, 9, true>), grid, block, 0, st, pack);
+    } else if (small) hipLaunchKernelGGL((ac_decode_ring_kernel<1>), grid, block, 0, st, pack);
     else if (crowd) hipLaunchKernelGGL((ac_decode_ring_kernel<4, 3>), grid, block, 0, st, pack);
     else hipLaunchKernelGGL((ac_decode_ring_kernel<4>), grid, block, 0, st, pack);
     return l3c::check_launch("ac_decode_ring_kernel<generic>");
@@ -1779,6 +1972,9 @@ int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_strea
             a.win = WindowCtx{q.window_stats_in, q.window_stats_out, q.P, q.sym_all, q.targets, q.HW, q.pix0, q.C, q.K, q.c};
         }
     }
+    for (int i = 0; i < n_parts; ++i)   // one kernel decodes window-row and full-row streams side by side: its full-row body is the 256-symbol one
+        for (int j = 0; j < n_parts; ++j)
+            L3C_REQUIRE(!parts[i].window_stats_in || parts[j].Lp == 257, "a call with window rows: every part must code the 256-symbol alphabet (Lp 257)");
     return launch_ring_decode(pack, n_parts, /*fast_pass=*/parts[0].not_monotone_flag != nullptr, l3c::as_stream(stream));
 }
 

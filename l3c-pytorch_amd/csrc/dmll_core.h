@@ -122,14 +122,23 @@ __device__ __forceinline__ uint32_t cdf_quantise(float cdf, float scale, int l) 
 //     1 <= x' <= 62           symbol w0 + x', interval [e[x'], e[x' + 1]) -- exactly the full row's
 //     x' == 0                 symbol <= w0: taken as exact (symbol 0, interval [e[0], e[1])) iff w0 == 0, otherwise a MISS
 //     x' == 63                symbol >= w0 + 63: exact (the top symbol 255, interval [e[63], 2^16)) iff w0 == kWinMaxOffset, else a MISS
-// On a miss the decoder evaluates the full row of that pixel itself (the functions above: the same bits).  Which form the rows of an
+// On a miss the decoder evaluates further entries of that pixel's row itself (the functions above: the same bits): the next 64 in the
+// direction of the miss, as another window, until the symbol is inside (csrc/ac_kernels.hip: window_row_at).  Which form the rows of an
 // image's chunk have is a pure function of the miss count the decoder reported two chunks earlier (see use_window).
 constexpr int kWinLp = 65;
 constexpr int kWinTop = 63;
 constexpr int kWinMaxOffset = 192;      // 256 - 64
 
-__host__ __device__ __forceinline__ bool use_window(int prev_misses, long long n_sym) {
-    return prev_misses >= 0 && (long long)prev_misses * 64 <= n_sym;     // unknown (negative) or > 1/64 of the symbols missed: full rows
+// Statistics word of a (stream, chunk): the number of misses (of would-be misses when its rows were full), with kWinBad set when that is
+// more than 1/64 of the chunk's symbols; negative = unknown.  The WRITER (the chunk's decoder) judges the rate against its own chunk
+// length, so that chunks of different lengths (the short probe chunks a stream starts with) need no bookkeeping on the reader's side.
+constexpr int kWinBad = 0x40000000;
+__host__ __device__ __forceinline__ bool use_window(int stat) { return stat >= 0 && stat < kWinBad; }
+// one_in: the rate above which the chunk counts as bad -- 1/64 for a stream that is on window rows (it stays), 1/128 for one on full
+// rows (it enters): the hysteresis keeps streams near the limit from flipping, and an estimate from full rows is a sample.
+__host__ __device__ __forceinline__ int window_stat(unsigned misses, unsigned n_sym, unsigned one_in) {
+    const unsigned m = misses < (unsigned)kWinBad ? misses : (unsigned)kWinBad - 1u;
+    return (int)((unsigned long long)misses * one_in <= n_sym ? m : (m | (unsigned)kWinBad));
 }
 
 // offset of the window around the mixture's mean (sum_k pi_k mu_k, sequential): symbols w0 + 1 .. w0 + 62 decode without a miss

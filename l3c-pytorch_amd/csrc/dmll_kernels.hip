@@ -32,6 +32,44 @@ using l3c::mix_component_e;
 using l3c::cdf_term;
 using l3c::cdf_quantise;
 
+// ---- P tile -> LDS ------------------------------------------------------------------------------------------------------
+// npix pixel rows of Kp floats (contiguous in memory) into tile[pixel][ld = Kp + 1] (the odd stride keeps the per-pixel column reads of
+// the compute phases conflict-free).  Kp % 4 == 0 (the RGB scale: 120) and a 16-byte aligned source: one 16-byte load per four values and
+// one division per load -- by multiplication with a host-made reciprocal (exact for the < 2^16 indices of a tile) -- instead of a
+// 4-byte load and an integer division per value (round 5: the divisions were a quarter of the interval kernel's VALU work).
+struct TileDiv {
+    unsigned q4, magic;   // q4 = Kp / 4 (0: scalar fill); i / q4 == (i * magic) >> 20 for i < 65536 / ... (checked by the host)
+};
+static TileDiv tile_div(int Kp, int max_pix) {
+    TileDiv d{0u, 0u};
+    if (Kp % 4 != 0) return d;
+    const unsigned q = (unsigned)(Kp / 4);
+    const unsigned magic = ((1u << 20) + q - 1u) / q;
+    for (unsigned i = 0; i < (unsigned)max_pix * q; ++i)
+        if (i / q != (unsigned)(((unsigned long long)i * magic) >> 20)) return d;   // (never for the shapes of this path; falls back to scalar)
+    d.q4 = q;
+    d.magic = magic;
+    return d;
+}
+__device__ __forceinline__ void fill_tile(float *__restrict__ tile, const float *__restrict__ src, int npix, int Kp, int ld, TileDiv dv,
+                                          int tid, int nthreads) {
+    if (dv.q4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const float4 *src4 = reinterpret_cast<const float4 *>(src);
+        const int n4 = npix * (int)dv.q4;
+        for (int i = tid; i < n4; i += nthreads) {
+            const float4 v = src4[i];
+            const int p = (int)(((unsigned)i * dv.magic) >> 20);
+            float *dst = tile + p * ld + (i - p * (int)dv.q4) * 4;
+            dst[0] = v.x;
+            dst[1] = v.y;
+            dst[2] = v.z;
+            dst[3] = v.w;
+        }
+    } else {
+        for (int i = tid; i < npix * Kp; i += nthreads) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+    }
+}
+
 // ---- per-channel parameters (CDFOut) ---------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void channel_params_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
@@ -116,7 +154,7 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const float *__restrict_
 // as encode_intervals_kernel: identical entries.
 // win_stats (round 5; nullptr: the classic form above): per image the miss count its decoder reported two chunks earlier.  The rows of image
 // b then are WINDOW rows (csrc/dmll_core.h: 65 entries around the mixture's mean, a quarter of the sigmoids and of the bytes) when
-// use_window(win_stats[b], range_len) says so -- the decoder evaluates the same function of the same number -- and full rows otherwise,
+// use_window(win_stats[b]) says so -- the decoder evaluates the same function of the same number -- and full rows otherwise,
 // whose entry Lp - 1 (never read by any coder: the top symbol's upper bound is 2^16) then carries the window offset, so that a decoder
 // working on full rows can still count what a window would have missed.  Either way image b's rows start at its full-size slot
 // cdf + b * range_len * Lp.
@@ -124,11 +162,10 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
                                                                int rgb, int c, int64_t range0, int64_t range_len, int Lp,
                                                                uint16_t *__restrict__ cdf, int32_t *__restrict__ not_monotone,
-                                                               const int32_t *__restrict__ win_stats) {
+                                                               const int32_t *__restrict__ win_stats, TileDiv dv) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kTablePix][Kp + 1]
     __shared__ float s_pi[kTablePix][kMaxK], s_mu[kTablePix][kMaxK], s_inv[kTablePix][kMaxK];
-    __shared__ float s_max[kTablePix], s_den[kTablePix];
-    __shared__ int s_w0[kTablePix];
+    __shared__ float s_e[kTablePix][kMaxK], s_max[kTablePix];
     __shared__ float s_t[260];
     const int Kp = (rgb ? 4 : 3) * C * K;
     const int ld = Kp + 1;
@@ -137,16 +174,24 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
     const int64_t pix0 = range0 + off;
     const int npix = (int)((range_len - off) < kTablePix ? (range_len - off) : kTablePix);
     const int tid = threadIdx.x;
-    const bool window = win_stats && l3c::use_window(win_stats[b], range_len);   // uniform over the image's blocks
+    const bool window = win_stats && l3c::use_window(win_stats[b]);   // uniform over the image's blocks
     const float *src = P + (b * HW + pix0) * Kp;
-    for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+    fill_tile(tile, src, npix, Kp, ld, dv, tid, 256);
     for (int i = tid; i < Lp; i += 256) s_t[i] = targets[i];
     __syncthreads();
-    if (tid < npix) {
-        const float *px = tile + tid * ld;
-        const MixStats st = mix_stats([&](int ch) { return px[ch]; }, C, K, c);
-        s_max[tid] = st.max_logit;
-        s_den[tid] = st.denom;
+    // The mixture parameters of the 32 pixels, one (pixel, component) item per thread in both phases (round 5; one thread per pixel
+    // walked mix_stats before: 32 of 256 lanes busy for what is, with 65-entry rows, a third of the block's work).  Same operations in the
+    // same order as mix_stats / mix_component: the maximum by the same fmaxf chain, the softmax numerators e_k = expf(l_k - max) computed
+    // once, the denominator their SEQUENTIAL sum (every thread of a pixel adds the same ten values in the same order).
+    for (int i = tid; i < kTablePix * K; i += 256) {
+        const int p = i % kTablePix, k = i / kTablePix;
+        if (p < npix) {
+            const float *px = tile + p * ld;
+            float mx = px[c * K];
+            for (int j = 1; j < K; ++j) mx = fmaxf(mx, px[c * K + j]);
+            s_e[p][k] = expf(px[c * K + k] - mx);
+            if (k == 0) s_max[p] = mx;
+        }
     }
     __syncthreads();
     for (int i = tid; i < kTablePix * K; i += 256) {
@@ -161,56 +206,81 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
             }
             MixStats st;
             st.max_logit = s_max[p];
-            st.denom = s_den[p];
-            const MixComponent m = mix_component([&](int ch) { return px[ch]; }, st, C, K, rgb, c, k, x0, x1);
+            st.denom = 0.0f;
+            for (int j = 0; j < K; ++j) st.denom = st.denom + s_e[p][j];
+            const MixComponent m = mix_component_e([&](int ch) { return px[ch]; }, st, s_e[p][k], C, K, rgb, c, k, x0, x1);
             s_pi[p][k] = m.pi;
             s_mu[p][k] = m.mu;
             s_inv[p][k] = expf(-m.log_sigma);
         }
     }
     __syncthreads();
-    if (win_stats) {   // the window's offset per pixel: around the mixture's mean
-        if (tid < npix) {
-            float mean = 0.0f;
-            for (int k = 0; k < K; ++k) mean = mean + s_pi[tid][k] * s_mu[tid][k];
-            s_w0[tid] = l3c::window_offset(mean);
-        }
-        __syncthreads();
-    }
     const float scale = (float)(65536 - (Lp - 1));
-    const int Lr = window ? l3c::kWinLp : Lp;        // entries of a row as stored
-    const int count = npix * Lr;
-    uint16_t *out = cdf + b * range_len * Lp + off * Lr;
+    auto pixel_w0 = [&](int p) {   // the window's offset: around the mixture's mean sum_k pi_k mu_k (sequential)
+        float mean = 0.0f;
+        for (int k = 0; k < K; ++k) mean = mean + s_pi[p][k] * s_mu[p][k];
+        return l3c::window_offset(mean);
+    };
+    const int lane = tid & 63;
+    if (window) {
+        // WINDOW rows: 32 pixels x 64 evaluated entries = 8 per thread -- thread t: pixel t / 8, entries 8 (t % 8) .. + 7 of its window.  The
+        // pixel's parameters are read once per component for all eight entries; a pixel's row lives in eight adjacent lanes, so the
+        // monotonicity check needs the next lane's first entry and nothing else.
+        const int p = tid >> 3, q = tid & 7;
+        bool bad = false;
+        if (p < npix) {
+            const int w0 = pixel_w0(p);
+            const int l0 = w0 + q * 8;
+            float tt[8], acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                tt[i] = s_t[l0 + i];
+                acc[i] = 0.0f;
+            }
+            for (int k = 0; k < K; ++k) {
+                const float pi = s_pi[p][k], mu = s_mu[p][k], inv = s_inv[p][k];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] = acc[i] + cdf_term(pi, mu, inv, tt[i]);
+            }
+            uint32_t v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = cdf_quantise(acc[i], scale, l0 + i);
+            uint16_t *row = cdf + b * range_len * Lp + (off + p) * l3c::kWinLp + q * 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) row[i] = (uint16_t)v[i];
+            if (q == 7) row[8] = (uint16_t)w0;          // entry 64: the window's offset
+#pragma unroll
+            for (int i = 0; i < 7; ++i) bad = bad || !(v[i] < v[i + 1]);
+            const uint32_t next = (uint32_t)__shfl_down((int)v[0], 1, 64);   // entry 8 (q + 1) of the same pixel (q < 7: the same wavefront)
+            bad = bad || (q < 7 && !(v[7] < next));
+        } else {
+            (void)__shfl_down(0, 1, 64);
+        }
+        if (not_monotone && __any(bad) && lane == 0) atomicOr(not_monotone, 1);
+        return;
+    }
+    const int count = npix * Lp;
+    uint16_t *out = cdf + (b * range_len + off) * Lp;
     const bool aligned4 = ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
     // The strict-monotonicity check the decoder needs (l3c_cdf_check_monotone: entries 0 .. Lp-2 of every row) is done on the
     // entries while they are in registers instead of re-reading the table (a 24 GB pass per batch of 128 otherwise): a thread
     // holds entries e, e + 1; entry e + 2 is the next lane's first; what a wavefront's last lane needs comes from another
-    // wavefront or the next turn of this loop and goes through s_edge, checked after the loop.  (Window rows: entries 0 .. 63.)
+    // wavefront or the next turn of this loop and goes through s_edge, checked after the loop.
     __shared__ uint32_t s_edge[kTablePix * 260 / 128 + 2][2];   // per run of 128 entries: its first and its last entry
-    const int lane = tid & 63;
-    const int l_last = window ? l3c::kWinTop - 1 : Lp - 3;   // pairs (l, l + 1) checked for 0 <= l <= l_last
     bool bad = false;
     for (int e = tid * 2; e < count; e += 512) {
         uint32_t v[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ee = e + h < count ? e + h : e;
-            const int p = ee / Lr, lr = ee - p * Lr;
-            int l = lr;                       // index into the full row
-            bool plain = true;
-            if (window) {
-                l = s_w0[p] + lr;
-                plain = lr != l3c::kWinLp - 1;
-            } else if (win_stats && lr == Lp - 1) {
-                plain = false;
-            }
-            if (plain) {
+            const int p = ee / Lp, l = ee - p * Lp;
+            if (win_stats && l == Lp - 1) {      // rows of a windowed part: the (never decoded) last entry carries the offset a window would have
+                v[h] = (uint32_t)pixel_w0(p);
+            } else {
                 const float t = s_t[l];
                 float acc = 0.0f;
                 for (int k = 0; k < K; ++k) acc = acc + cdf_term(s_pi[p][k], s_mu[p][k], s_inv[p][k], t);
                 v[h] = cdf_quantise(acc, scale, l);
-            } else {
-                v[h] = (uint32_t)s_w0[p];     // e[64] of a window row / e[Lp - 1] of a full row: the window's offset
             }
         }
         if (aligned4 && e + 1 < count) {
@@ -219,12 +289,12 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
             out[e] = (uint16_t)v[0];
             if (e + 1 < count) out[e + 1] = (uint16_t)v[1];
         }
-        if (not_monotone) {   // pairs (m, m + 1) inside a row: entry index mod Lr
-            const int l0 = e % Lr;
-            bad = bad || (e + 1 < count && l0 <= l_last && !(v[0] < v[1]));
+        if (not_monotone) {   // pairs (m, m + 1) with m <= Lp - 3 inside a row: entry index mod Lp
+            const int l0 = e % Lp;
+            bad = bad || (e + 1 < count && l0 <= Lp - 3 && !(v[0] < v[1]));
             const uint32_t next = (uint32_t)__shfl_down((int)v[0], 1, 64);   // entry e + 2 (lanes 0 .. 62)
-            const int l1 = l0 + 1 < Lr ? l0 + 1 : 0;
-            bad = bad || (lane < 63 && e + 2 < count && l1 <= l_last && !(v[1] < next));
+            const int l1 = l0 + 1 < Lp ? l0 + 1 : 0;
+            bad = bad || (lane < 63 && e + 2 < count && l1 <= Lp - 3 && !(v[1] < next));
             if (lane == 0) s_edge[e >> 7][0] = v[0];
             if (lane == 63) s_edge[e >> 7][1] = v[1];
         }
@@ -233,8 +303,8 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
         __syncthreads();
         const int runs = (count + 127) >> 7;   // run j: entries 128 j .. 128 j + 127; its last entry against the next run's first
         for (int j = tid; j + 1 < runs; j += 256) {
-            const int m = (128 * j + 127) % Lr;
-            bad = bad || (m <= l_last && !(s_edge[j][1] < s_edge[j + 1][0]));
+            const int m = (128 * j + 127) % Lp;
+            bad = bad || (m <= Lp - 3 && !(s_edge[j][1] < s_edge[j + 1][0]));
         }
         if (__any(bad) && lane == 0) atomicOr(not_monotone, 1);
     }
@@ -248,7 +318,7 @@ constexpr int kHeadPix = 64;  // == interval block length, so one block writes w
 // 6.8 ms per launch at batch 128 [PMC]: fewer wavefronts per CU for the LDS-bound tile fill outweigh the busier lanes.)
 __global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
-                                                               int rgb, int Lp, uint32_t *__restrict__ iv) {
+                                                               int rgb, int Lp, uint32_t *__restrict__ iv, TileDiv dv) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kHeadPix][Kp + 1]
     const int Kp = (rgb ? 4 : 3) * C * K;
     const int ld = Kp + 1;
@@ -258,7 +328,7 @@ __global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__re
     const int npix = (int)((HW - pix0) < kHeadPix ? (HW - pix0) : kHeadPix);
     const int tid = threadIdx.x;
     const float *src = P + (b * HW + pix0) * Kp;
-    for (int i = tid; i < npix * Kp; i += 256) tile[(i / Kp) * ld + (i % Kp)] = src[i];   // (a wavefront per pixel row instead: 4.4 -> 6.8 ms)
+    fill_tile(tile, src, npix, Kp, ld, dv, tid, 256);   // (a wavefront per pixel row instead: 4.4 -> 6.8 ms)
     __syncthreads();
     const float scale = (float)(65536 - (Lp - 1));
     const int64_t n_streams = (int64_t)gridDim.y * C;
@@ -471,7 +541,7 @@ int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets,
     L3C_REQUIRE(lds <= 48 * 1024, "Kp too large for the LDS tile");
     const dim3 grid((unsigned)((npix + kTablePix - 1) / kTablePix), (unsigned)B);
     hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, c,
-                       pix0, npix, Lp, cdf, not_monotone, window_stats);
+                       pix0, npix, Lp, cdf, not_monotone, window_stats, tile_div(Kp, kTablePix));
     int rc = l3c::check_launch("cdf_table_from_P_kernel");
     return rc;   // (the kernel has checked the rows while it held them: not_monotone)
 }
@@ -488,7 +558,7 @@ int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *t
     L3C_REQUIRE(lds <= 64 * 1024, "Kp too large for the LDS tile");
     const dim3 grid((unsigned)((HW + kHeadPix - 1) / kHeadPix), (unsigned)B);
     hipLaunchKernelGGL(encode_intervals_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K,
-                       rgb, Lp, intervals);
+                       rgb, Lp, intervals, tile_div(Kp, kHeadPix));
     return l3c::check_launch("encode_intervals_kernel");
 }
 

@@ -88,7 +88,7 @@ def test_window_rows_are_slices_of_the_full_rows(c):
     t = _targets()
     full = ops.dmll_cdf_table(P, sym, t, 3, K, True, c, 0, HW).cpu().numpy().view(np.uint16).astype(np.int64)      # (B, HW, 257)
     # image 0: window rows; image 1: unknown statistics -> full rows; image 2: too many misses -> full rows
-    stats = torch.tensor([0, -1, HW], dtype=torch.int32, device='cuda')
+    stats = torch.tensor([0, -1, HW | 0x40000000], dtype=torch.int32, device='cuda')     # (bit 30: more than 1/64 of the chunk missed)
     flag = torch.zeros(1, dtype=torch.int32, device='cuda')
     mixed = ops.dmll_cdf_table(P, sym, t, 3, K, True, c, 0, HW, flag, window_stats=stats).cpu().numpy().view(np.uint16).astype(np.int64)
     assert int(flag.item()) == 0
@@ -130,12 +130,12 @@ def test_every_symbol_a_miss_and_no_symbol_a_miss(H, W, chunks):
             got, stats = _decode_channel(P, sym, payloads, c, zeros, chunks=chunks)
             assert torch.equal(got, sym[:, c].reshape(B, HW)), (c, expect_all_miss)
             last = _bounds(HW, chunks)[-1][1]
-            assert stats.tolist() == [last if expect_all_miss else 0] * B, (stats.tolist(), last)
+            assert stats.tolist() == [(last | 0x40000000) if expect_all_miss else 0] * B, (stats.tolist(), last)   # bit 30: too many for a window
 
 
 def test_full_rows_count_what_a_window_would_have_missed():
-    """statistics -1 (unknown): full rows, and the decoder reports how many symbols a window would have missed -- the number the
-    window decoder reports for the same stream."""
+    """statistics -1 (unknown): full rows, and the decoder reports how many symbols a window would have missed -- an estimate (every
+    fourth ring block is looked at, x 4) of the number the window decoder counts for the same stream."""
     rng = np.random.RandomState(3)
     B, H, W = 2, 32, 48
     HW = H * W
@@ -146,7 +146,10 @@ def test_full_rows_count_what_a_window_would_have_missed():
         got_w, stats_w = _decode_channel(P, sym, payloads, c, torch.zeros(B, dtype=torch.int32, device='cuda'))
         got_f, stats_f = _decode_channel(P, sym, payloads, c, torch.full((B,), -1, dtype=torch.int32, device='cuda'))
         assert torch.equal(got_w, sym[:, c].reshape(B, HW)) and torch.equal(got_f, got_w)
-        assert stats_w.tolist() == stats_f.tolist() and 0 < min(stats_w.tolist()) and max(stats_w.tolist()) < HW
+        w, f = [v & 0x3FFFFFFF for v in stats_w.tolist()], [v & 0x3FFFFFFF for v in stats_f.tolist()]
+        assert 0 < min(w) and max(w) < HW
+        for a, e in zip(w, f):
+            assert a / 2.5 <= e <= a * 2.5, (w, f)
 
 
 def test_unvalidated_table_and_garbage_streams_decode_alike_in_both_row_forms():
@@ -196,15 +199,15 @@ def test_windowed_decode_of_the_bench_images_in_every_mode(blueprint):
         dec, _ = bc.decode_batch(files)
         assert torch.equal(dec.cpu(), imgs.long()), (blueprint.ckpt_name, mode)
         if mode == 'auto':
-            stats = bc.last_rgb_window_stats.cpu().numpy()             # (3, chunks + 2, 8)
+            stats = bc.last_rgb_window_stats.cpu().numpy()             # (3, chunks + 2, 8): slot j + 2 = chunk j (two probes first)
             assert (stats[:, :2] == -1).all() and (stats[:, 2:] >= 0).all()
-            n = H * W // (stats.shape[1] - 2)
-            share = stats[:, 2:].astype(np.float64) / n                   # misses per symbol, per channel / chunk / image
-            print(blueprint.ckpt_name, 'misses per symbol, mean over chunks and images, R G B:', share.mean(axis=(1, 2)))
+            good = (stats[:, 2:] & 0x40000000) == 0                       # at most 1/64 of the chunk's symbols missed: window rows two chunks on
+            print(blueprint.ckpt_name, 'share of (chunk, image) pairs that qualify for window rows, R G B:', good.mean(axis=(1, 2)),
+                  'misses in the regular chunks, mean R G B:', (stats[:, 4:] & 0x3FFFFFFF).mean(axis=(1, 2)))
             if blueprint.ckpt_name == 'calibrated':
-                assert (share < 1 / 64).mean() > 0.7                      # most (chunk, image) pairs qualify for window rows
+                assert good.mean() > 0.7
             else:
-                assert share[:2].mean() > 0.5                             # mixtures in the wrong place: R and G stay on full rows
+                assert good[:2].mean() < 0.5                              # mixtures in the wrong place: R and G stay on full rows
     # one image alone (32 chunks, no overlapped schedule) and its batch-invariance
     one, _ = Bitcoding(blueprint).decode_batch(files[3:4])
     assert torch.equal(one.cpu(), imgs[3:4].long())

@@ -11,7 +11,12 @@ import torch  # noqa: E402
 import bench  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-cfg, sd, bp, bc, synthetic = bench.build_path('cr', 0, True)
+CALIBRATED = not (len(sys.argv) > 2 and sys.argv[2] == 'default')       # second argument `default`: the default-init checkpoint
+cfg, sd, bp, bc, synthetic = bench.build_path('cr', 0, CALIBRATED)
+if len(sys.argv) > 3:                                                    # third argument: rgb_window mode (auto / always / never)
+    bc.rgb_window = sys.argv[3]
+if len(sys.argv) > 4:                                                    # fourth argument: chunks per RGB channel
+    bc.RGB_CHUNKS = int(sys.argv[4])
 imgs = torch.stack([synthetic.make_image(512, 768, i, 'natural') for i in range(B)]).cuda()
 enc = bc.encode_batch(imgs.float())
 files = enc.to_bytes()

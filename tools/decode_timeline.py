@@ -1,0 +1,50 @@
+#!/usr/bin/env python
+"""Development: time line of the LAST decode_batch of a rocprofv3 kernel trace (tools/decode_profile.py) -- per kernel: launches,
+busy time (union of its launches), first start / last end relative to the decode's first kernel; and the GPU-idle gaps.
+
+    rocprofv3 --kernel-trace -d D -o run --output-format csv -- python tools/decode_profile.py 128 ; python tools/decode_timeline.py D"""
+import csv
+import glob
+import os
+import re
+import sys
+from decode_overlap import union, length
+
+
+def short(n):
+    n = re.sub(r'\(anonymous namespace\)::', '', n)
+    n = re.sub(r'\(.*', '', n).replace('void ', '')
+    return n[:70]
+
+
+def main():
+    rows = []
+    for f in glob.glob(os.path.join(sys.argv[1], '**', '*kernel_trace.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), short(r['Kernel_Name'])))
+    rows.sort()
+    cut = rows[0][0]
+    end = rows[0][1]
+    for a, b, n in rows:
+        if a - end > 100e6:
+            cut = a
+        end = max(end, b)
+    rows = [r for r in rows if r[0] >= cut]
+    t0 = rows[0][0]
+    ms = 1e-6
+    names = {}
+    for a, b, n in rows:
+        names.setdefault(n, []).append((a, b))
+    print('last decode: {} launches, first start to last end {:.1f} ms, some kernel running {:.1f} ms'.format(
+        len(rows), (max(b for _, b, _ in rows) - t0) * ms, length(union([(a, b) for a, b, _ in rows])) * ms))
+    print('{:72s} {:>5s} {:>9s} {:>9s} {:>9s} {:>9s}'.format('kernel', 'n', 'busy ms', 'sum ms', 'first', 'last end'))
+    for n, iv in sorted(names.items(), key=lambda kv: min(a for a, _ in kv[1])):
+        print('{:72s} {:5d} {:9.1f} {:9.1f} {:9.1f} {:9.1f}'.format(n, len(iv), length(union(iv)) * ms, sum(b - a for a, b in iv) * ms,
+                                                                     (min(a for a, _ in iv) - t0) * ms, (max(b for _, b in iv) - t0) * ms))
+    u = union([(a, b) for a, b, _ in rows])
+    gaps = sorted(((c - b, b - t0) for (a, b), (c, d) in zip(u, u[1:])), reverse=True)[:8]
+    print('largest idle gaps (ms, at ms):', [(round(g * ms, 2), round(at * ms, 1)) for g, at in gaps])
+
+
+if __name__ == '__main__':
+    main()
