@@ -592,12 +592,12 @@ def extra_legs(args):
         worst['decode'] = {k: wc['decode'][k] for k in ('value', 'unit', 'seconds', 'lossless', 'batch1_seconds')}
     worst['note'] = ('default-init checkpoint: mixtures near 0 for pixels in 0..255, the R and G streams sit at the 16-bit probability '
                      'floor -- 2.6x the calibrated checkpoint\'s bitstream volume, ~6x a trained model\'s')
-    ds = _sub_bench(['--config', 'dataset', '--images', '200', '--steps', '1', '--warmup', '1', '--checkpoint', args.checkpoint])
-    lg = _sub_bench(['--config', 'large', '--steps', '2', '--warmup', '1', '--checkpoint', args.checkpoint])
-    keys = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'bpsp', 'megapixels', 'round_trip_of_2_images', 'config')
+    ds = _sub_bench(['--config', 'dataset', '--images', '200', '--steps', '3', '--warmup', '1', '--checkpoint', args.checkpoint])
+    lg = _sub_bench(['--config', 'large', '--steps', '4', '--warmup', '1', '--checkpoint', args.checkpoint])
+    keys = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'bpsp', 'megapixels', 'round_trip_of_2_images', 'per_step', 'config')
     return {'worst_case_coder': worst,
             'configs': {'dataset': dict(pick(ds, keys), reduced='200 of the 500 images of BASELINE.json config 4 (python bench.py --config dataset runs all 500; the fill and drain of the host pipeline weigh more on the shorter set)'),
-                        'large': dict(pick(lg, keys), reduced='2 steps of BASELINE.json config 5 (python bench.py --config large)')}}
+                        'large': dict(pick(lg, keys), reduced='4 steps of BASELINE.json config 5 (python bench.py --config large)')}}
 
 
 # ---- dataset: 500 differently sized images, end to end from host images to host files ---------------------------------------------
@@ -614,11 +614,17 @@ def run_dataset(args, ranks):
     with single_thread():
         imgs = {i: synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural') for i in mine}     # host uint8
 
+    step_seconds = []          # every step ends with its files on the host: its wall time is a measurement of its own
+
     def step():
-        return dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'],
-                                        canvas=os.environ.get('L3C_CANVAS', '0') != '0')
+        t0 = time.perf_counter()
+        r = dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'],
+                                     canvas=os.environ.get('L3C_CANVAS', '0') != '0')
+        step_seconds.append(time.perf_counter() - t0)
+        return r
 
     elapsed, (files, n_shapes, n_launches) = timed(ranks, step, args.steps, args.warmup)
+    step_seconds = step_seconds[-args.steps:]
     pixels = sum(sizes[i][0] * sizes[i][1] for i in mine)
     bits = sum(len(files[i]) for i in mine) * 8
     tot_px, tot_bits = ranks.sum_over_ranks([pixels, bits])
@@ -641,6 +647,10 @@ def run_dataset(args, ranks):
                     'sharding': 'largest-first greedy on pixel counts (helpers/sharding.shard_balanced), replicas only',
                     'pixels_on_rank0_over_mean': round(pixels * ranks.world / tot_px, 4)},
             bpsp=round(tot_bits / (3 * tot_px), 4), megapixels=round(tot_px / 1e6, 1), round_trip_of_2_images='lossless',
+            per_step={'seconds_rank0': [round(t, 4) for t in step_seconds],
+                      'mpix_per_s_rank0_best': round(pixels / 1e6 / min(step_seconds), 2),
+                      'mpix_per_s_rank0_median': round(pixels / 1e6 / sorted(step_seconds)[len(step_seconds) // 2], 2),
+                      'mpix_per_s_rank0_worst': round(pixels / 1e6 / max(step_seconds), 2)},
             device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     return result
 

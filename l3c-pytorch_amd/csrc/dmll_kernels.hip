@@ -316,7 +316,7 @@ constexpr int kHeadPix = 64;  // == interval block length, so one block writes w
 
 // (Tried: kHeadPix * C threads per block -- one (pixel, channel) item per thread, no idle lanes in the compute phase: 4.4 ->
 // 6.8 ms per launch at batch 128 [PMC]: fewer wavefronts per CU for the LDS-bound tile fill outweigh the busier lanes.)
-__global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
+__global__ __launch_bounds__(320) void encode_intervals_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
                                                                int rgb, int Lp, uint32_t *__restrict__ iv, TileDiv dv) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kHeadPix][Kp + 1]
@@ -328,11 +328,12 @@ __global__ __launch_bounds__(256) void encode_intervals_kernel(const float *__re
     const int npix = (int)((HW - pix0) < kHeadPix ? (HW - pix0) : kHeadPix);
     const int tid = threadIdx.x;
     const float *src = P + (b * HW + pix0) * Kp;
-    fill_tile(tile, src, npix, Kp, ld, dv, tid, 256);   // (a wavefront per pixel row instead: 4.4 -> 6.8 ms)
+    const int nthreads = (int)blockDim.x;
+    fill_tile(tile, src, npix, Kp, ld, dv, tid, nthreads);   // (a wavefront per pixel row instead: 4.4 -> 6.8 ms)
     __syncthreads();
     const float scale = (float)(65536 - (Lp - 1));
     const int64_t n_streams = (int64_t)gridDim.y * C;
-    for (int w = tid; w < kHeadPix * C; w += 256) {
+    for (int w = tid; w < kHeadPix * C; w += nthreads) {
         const int p = w % kHeadPix, c = w / kHeadPix;
         uint32_t word0 = 0, word1 = 0;   // the stream's lane pair reads one word per role (csrc/ac_core.h: role_word)
         if (p < npix) {
@@ -557,7 +558,15 @@ int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *t
     const size_t lds = (size_t)kHeadPix * (Kp + 1) * sizeof(float);
     L3C_REQUIRE(lds <= 64 * 1024, "Kp too large for the LDS tile");
     const dim3 grid((unsigned)((HW + kHeadPix - 1) / kHeadPix), (unsigned)B);
-    hipLaunchKernelGGL(encode_intervals_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K,
+    // one (pixel, channel) item per thread: 192 threads for the RGB scale, 320 for the bottleneck scales (every lane busy in the compute
+    // phase; with 256 threads a quarter of them idled through it).  [round 2 measured this form SLOWER, 4.4 -> 6.8 ms per launch, when the
+    // tile fill -- a division per value -- dominated; round 5, with the 16-byte fill: see profiles/r05_interval_kernel_threads.log]
+#ifdef L3C_IV_THREADS_256
+    const int nthreads = 256;
+#else
+    const int nthreads = kHeadPix * C <= 320 ? kHeadPix * C : 256;
+#endif
+    hipLaunchKernelGGL(encode_intervals_kernel, grid, dim3(nthreads), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K,
                        rgb, Lp, intervals, tile_div(Kp, kHeadPix));
     return l3c::check_launch("encode_intervals_kernel");
 }

@@ -31,8 +31,11 @@ def losses_bpsp(out, hp=net.L3C_HYPER, num_subpixels=None):
     return [float(c) / conv for c in costs] + [final / conv]
 
 
-def encode(img, sd, hp=net.L3C_HYPER, padding_tuple=(0, 0, 0, 0)):
-    """img: (1,3,H,W) int64 (already padded to a multiple of 2**num_scales) -> bytes of the .l3c file."""
+def encode(img, sd, hp=net.L3C_HYPER, padding_tuple=(0, 0, 0, 0), coder=None):
+    """img: (1,3,H,W) int64 (already padded to a multiple of 2**num_scales) -> bytes of the .l3c file.
+    coder: None = the C restatement (oracle/ac.py), or a callable(table (N, Lp) int16 array, symbols (N,) int16 array) -> bytes, e.g.
+    the REFERENCE's compiled coder (oracle/cpu_baseline.py times the port's forward and tables with the reference's own torchac.cpp)."""
+    enc = coder if coder is not None else ac.encode
     out = net.forward(img.float(), sd, hp)
     zs = dmll.z_spec(hp.levels_range, hp.L)
     chunks = [struct.pack('<4H', *padding_tuple)]
@@ -43,7 +46,7 @@ def encode(img, sd, hp=net.L3C_HYPER, padding_tuple=(0, 0, 0, 0)):
         if scale == hp.num_scales:
             table = cdf.uniform_cdf_table(H, W, hp.L)
             for c in range(C):
-                b = ac.encode(table.numpy(), S[0, c].to(torch.int16).numpy())
+                b = enc(table.numpy(), S[0, c].to(torch.int16).numpy())
                 chunks += [struct.pack('<I', len(b)), b]
         else:
             spec = dmll.RGB if scale == 0 else zs
@@ -52,7 +55,7 @@ def encode(img, sd, hp=net.L3C_HYPER, padding_tuple=(0, 0, 0, 0)):
             for c in range(C):
                 pi, mu, ls = dmll.params_for_channel(spec, out.P[scale], c, C, x)
                 table = cdf.mixture_cdf_table(pi, targets, mu, ls)
-                b = ac.encode(table.numpy(), S[0, c].to(torch.int16).numpy())
+                b = enc(table.numpy(), S[0, c].to(torch.int16).numpy())
                 chunks += [struct.pack('<I', len(b)), b]
         chunks.append(MAGIC)
     return b''.join(chunks)
