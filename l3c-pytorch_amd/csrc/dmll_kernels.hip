@@ -558,13 +558,14 @@ int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *t
     const size_t lds = (size_t)kHeadPix * (Kp + 1) * sizeof(float);
     L3C_REQUIRE(lds <= 64 * 1024, "Kp too large for the LDS tile");
     const dim3 grid((unsigned)((HW + kHeadPix - 1) / kHeadPix), (unsigned)B);
-    // one (pixel, channel) item per thread: 192 threads for the RGB scale, 320 for the bottleneck scales (every lane busy in the compute
-    // phase; with 256 threads a quarter of them idled through it).  [round 2 measured this form SLOWER, 4.4 -> 6.8 ms per launch, when the
-    // tile fill -- a division per value -- dominated; round 5, with the 16-byte fill: see profiles/r05_interval_kernel_threads.log]
+    // Threads per block [measured, round 5, profiles/r05_interval_kernel_threads.log, batch 32]: the bottleneck scales' 320 (pixel, channel)
+    // items on 320 threads -- one each -- 1.28 ms against 1.40 ms on 256 (where a second, quarter-full turn of the compute loop follows the
+    // first); the RGB scale's 192 items stay on 256 threads: 2.16 ms against 2.30 ms on 192 (the fourth wavefront idles through the compute
+    // phase but helps fill the tile).
 #ifdef L3C_IV_THREADS_256
     const int nthreads = 256;
 #else
-    const int nthreads = kHeadPix * C <= 320 ? kHeadPix * C : 256;
+    const int nthreads = (kHeadPix * C > 256 && kHeadPix * C <= 320) ? kHeadPix * C : 256;
 #endif
     hipLaunchKernelGGL(encode_intervals_kernel, grid, dim3(nthreads), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K,
                        rgb, Lp, intervals, tile_div(Kp, kHeadPix));
