@@ -279,6 +279,10 @@ int l3c_conv_mfma(const l3c_conv_desc *desc_host, l3c_stream_t stream);
  * prob_clf.py:71-74); differs from the direct convolution by fp32 rounding (measured: the L3C forward stays within 5e-6 of the
  * fp32 reference relative to each tensor's largest magnitude, profiles/r03_wino_f43_numerics.log).  Cin % 16 == 0; input and
  * packed weights 16-byte aligned, input channel stride / offset multiples of 4; output / residual: any channel slice.
+ * L3C_EPI_PIXEL_SHUFFLE (the 64 -> 256 tail of edsr.Upsampler + nn.PixelShuffle(2), ABI version 3): Cout == 256, and `packed_w` must be
+ * packed from the weights in SUB-PIXEL-MAJOR order -- row 64 s + oc of the tensor handed to l3c_conv_wino4_pack_weights = row 4 oc + s of
+ * the layer's OIHW weights (s = 2 i + j: the sub-pixel, oc: the output channel) -- so that block s of a tile computes 64 adjacent output
+ * channels of one sub-pixel and stores 64-byte runs; `bias` stays in the layer's own order.
  */
 int64_t l3c_conv_wino4_packed_words(int Cout, int Cin);
 int l3c_conv_wino4_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);

@@ -87,8 +87,12 @@ __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                     for (int ci = 0; ci < 3; ++ci) {
+                        // fused multiply-adds (round 5: the file is built with -ffp-contract=off, and as separate multiplications and
+                        // additions these 27 x 4 terms made the kernel VALU-bound at 2.8 TB/s: ~250 instructions per 16-byte store)
                         const float v = s_in[(ci * IH + r + ky) * IW + c + kx];
-                        acc = acc + v * wreg[(ky * 3 + kx) * 3 + ci];
+                        const f32x4 wq = wreg[(ky * 3 + kx) * 3 + ci];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(v, wq[e], acc[e]);
                     }
             *reinterpret_cast<f32x4 *>(&out[(((size_t)b * H + y) * W + x) * Cf + q * 4]) = acc + bias;
         }

@@ -195,7 +195,12 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const int n_cc = p.Cin / CK;
 
     // block -> (image, output-channel chunk, sub-grid, tile row, group of tiles)
+    // (the output-channel chunk is the FASTEST index: the blocks that compute different output channels of one tile -- four for the
+    // 64 -> 256 PixelShuffle tail -- are neighbours in the launch order of one XCD and share the tile's input patches through its L2)
     unsigned w = (unsigned)xcd_remap4(blockIdx.x, p.total_blocks);
+    const unsigned w_c = p.div_chunks.div(w);
+    const int chunk_o = (int)(w - w_c * (unsigned)p.n_chunks_o);
+    w = w_c;
     const unsigned groups = (unsigned)(p.groups_x * p.tiles_y);
     const unsigned w_t = p.div_groups.div(w);
     const unsigned grp = w - w_t * groups;
@@ -203,8 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const int dl = p.dil_log2, dil = 1 << dl;
     const int phase = (int)(w & ((1u << (2 * dl)) - 1));
     w >>= 2 * dl;
-    const int b = (int)p.div_chunks.div(w);
-    const int chunk_o = (int)(w - (unsigned)b * (unsigned)p.n_chunks_o);
+    const int b = (int)w;
     const int py = phase >> dl, px = phase & (dil - 1);
     const unsigned t_y = p.div_groups_x.div(grp);
     const int sy0 = (int)t_y * OT;                                         // tile row origin in sub-grid coordinates
@@ -311,7 +315,11 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     f32x4 a_ring[AR];
 
     f32x4 acc[36];
-    const int co_lane = chunk_o * 64 + wave * 16 + (lane & 15);
+    // PixelShuffle: block chunk_o computes SUB-PIXEL chunk_o of the 2 x 2 output pixels -- its 64 conv channels are 4 oc + chunk_o, oc = 0..63
+    // (the caller packs the weights in that order, see l3c_conv_wino4) -- so that a wavefront's 16 channels are 16 ADJACENT output channels
+    // of one output pixel: 64-byte runs per pixel like every other variant (round 5; before, a wavefront held the 4 sub-pixels of 4 output
+    // channels and every output pixel's 256-byte line left in sixteen 16-byte pieces from sixteen wavefronts: 2.8x the algorithmic bytes)
+    const int co_lane = SHUFFLE ? 4 * (wave * 16 + (lane & 15)) + chunk_o : chunk_o * 64 + wave * 16 + (lane & 15);
     const float bias_init = co_lane < p.Cout ? p.bias[co_lane] : 0.0f;
 
     // ---- output addressing: ONE uniform descriptor at the block's first output row, a per-lane byte offset, uniform offsets
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const int col_b = S * dil * p.out_cstride * 4, row_b = S * dil * (S * p.Wo) * p.out_cstride * 4;   // one conv pixel / row on
     const int rcol_b = dil * p.res_cstride * 4, rrow_b = dil * p.Wo * p.res_cstride * 4;
     const auto o_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        p.out + (((size_t)b * (S * p.Ho) + S * (py + dil * sy0)) * (S * p.Wo) + S * px) * p.out_cstride + p.out_coff +
-            (SHUFFLE ? chunk_o * 16 : chunk_o * 64), 0, OOB, 0x00020000);
+        p.out + (((size_t)b * (S * p.Ho) + S * (py + dil * sy0) + (SHUFFLE ? (chunk_o >> 1) : 0)) * (S * p.Wo) + S * px + (SHUFFLE ? (chunk_o & 1) : 0)) *
+                    p.out_cstride + p.out_coff + (SHUFFLE ? 0 : chunk_o * 64), 0, OOB, 0x00020000);
     const auto r_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(RES ? p.res + (((size_t)b * p.Ho + py + dil * sy0) * p.Wo + px) * p.res_cstride + p.res_coff + chunk_o * 64 : p.bias),
         0, RES ? OOB : 0, 0x00020000);
@@ -560,20 +568,19 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
             const int q = ln >> 4, n = ln & 15;
             const int q2 = ln >> 4, j2 = (ln >> 2) & 3, c4 = ln & 3;   // store layout: pixel (4 q2 + i, 4 r + j2), channels 4 c4 ..
             const int sx0 = (tx_first + t) * OT;
-            const bool lane_ok = chunk_o * 64 + wave * 16 + (SHUFFLE ? 0 : c4 * 4) < p.Cout;   // Cout % 4 (shuffle: % 16) == 0
-            int o_lane, r_lane = 0;
-            if constexpr (SHUFFLE)   // conv channel co -> output pixel (2 oy + (co >> 1 & 1), 2 ox + (co & 1)), channel co >> 2: lane
-                                     // (pixel, sub-pixel c4) stores the four output channels of this wavefront's 16 conv channels
-                o_lane = 4 * q2 * row_b + j2 * col_b + ((c4 >> 1) * (2 * p.Wo) + (c4 & 1)) * p.out_cstride * 4 + wave * 16;
-            else
-                o_lane = 4 * q2 * row_b + j2 * col_b + (wave * 16 + c4 * 4) * 4;
+            // Cout % 4 == 0 (shuffle: the block's channels are output channels 0 .. Cout / 4 - 1 of its sub-pixel)
+            const bool lane_ok = SHUFFLE ? 4 * (wave * 16 + c4 * 4) < p.Cout : chunk_o * 64 + wave * 16 + c4 * 4 < p.Cout;
+            int r_lane = 0;
+            // (shuffle: conv pixel (y, x) -> output pixel (2 y + chunk_o / 2, 2 x + chunk_o % 2): row_b / col_b step two output pixels, the
+            // sub-pixel sits in the descriptor's base)
+            const int o_lane = 4 * q2 * row_b + j2 * col_b + (wave * 16 + c4 * 4) * 4;
             if constexpr (RES) r_lane = 4 * q2 * rrow_b + j2 * rcol_b + (wave * 16 + c4 * 4) * 4;
             const int oy_l = py + dil * (sy0 + 4 * q2), ox_l = px + dil * (sx0 + j2);
             // window of this wavefront, in V[1]: [row of the round][q][j][16 channels] (a 2-way bank conflict on the four-byte writes -- lanes
             // n and n + 32 q -- costs a ds_write_b32 nothing; the 16-byte reads cover 1 KB contiguously)
             constexpr int ER = L3C_W4_EPI_ROWS;
             float *win = lds + V_OFF1 + wave * (ER * WIN_ROW_FLOATS);
-            float *w_dst = win + q * 64 + (SHUFFLE ? (n & 3) * 4 + (n >> 2) : n);   // shuffle: channels of one sub-pixel adjacent
+            float *w_dst = win + q * 64 + n;
             const float *w_src = win + q2 * 64 + j2 * 16 + c4 * 4;
             auto lane_off = [&](int base, int r, int i) {
                 const bool ok = lane_ok && oy_l + dil * i < Ho_b && ox_l + dil * 4 * r < Wo_b;
@@ -763,8 +770,9 @@ static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int 
                 "residual channel stride/offset must be multiples of 4 (16-byte loads)");
     L3C_REQUIRE(((uintptr_t)d->in | (uintptr_t)d->out | (uintptr_t)d->packed_w | ((d->epilogue & L3C_EPI_RESIDUAL) ? (uintptr_t)d->residual : 0)) % 16 == 0,
                 "input, output, residual and packed weights must be 16-byte aligned");
-    L3C_REQUIRE(d->Cout % ((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? 16 : 4) == 0,
-                "Cout must be a multiple of 4 (pixel shuffle: 16): a lane stores four adjacent channels");
+    L3C_REQUIRE(d->Cout % 4 == 0, "Cout must be a multiple of 4: a lane stores four adjacent channels");
+    L3C_REQUIRE(!(d->epilogue & L3C_EPI_PIXEL_SHUFFLE) || d->Cout == 256,
+                "pixel shuffle: Cout must be 256 (four sub-pixel blocks of 64 output channels; weights packed sub-pixel-major)");
     L3C_REQUIRE((d->epilogue & ~(L3C_EPI_RELU | L3C_EPI_RESIDUAL | L3C_EPI_PIXEL_SHUFFLE)) == 0, "unknown epilogue bits");
     L3C_REQUIRE(d->in_coff + d->Cin <= d->in_cstride, "input channel slice out of range");
     L3C_REQUIRE(d->out_coff + ((d->epilogue & L3C_EPI_PIXEL_SHUFFLE) ? d->Cout / 4 : d->Cout) <= d->out_cstride, "output channel slice out of range");

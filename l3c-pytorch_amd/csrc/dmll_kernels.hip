@@ -42,6 +42,9 @@ struct TileDiv {
 };
 static TileDiv tile_div(int Kp, int max_pix) {
     TileDiv d{0u, 0u};
+#ifdef L3C_IV_SCALAR_FILL
+    return d;       // (A/B builds: the scalar fill of rounds 1-4)
+#endif
     if (Kp % 4 != 0) return d;
     const unsigned q = (unsigned)(Kp / 4);
     const unsigned magic = ((1u << 20) + q - 1u) / q;
@@ -51,22 +54,51 @@ static TileDiv tile_div(int Kp, int max_pix) {
     d.magic = magic;
     return d;
 }
-__device__ __forceinline__ void fill_tile(float *__restrict__ tile, const float *__restrict__ src, int npix, int Kp, int ld, TileDiv dv,
-                                          int tid, int nthreads) {
+// NT threads (a compile-time constant) fill; the loads of a batch of U turns are all issued before the first value is stored, so that the
+// batch pays one memory round trip (with a run-time stride the compiler keeps one load in flight per turn: the 150-channel tiles of
+// the bottleneck scales then took 30 round trips, twice the time of the whole kernel before).
+template <int NT>
+__device__ __forceinline__ void fill_tile(float *__restrict__ tile, const float *__restrict__ src, int npix, int Kp, int ld, TileDiv dv, int tid) {
     if (dv.q4 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        constexpr int U = 4;
         const float4 *src4 = reinterpret_cast<const float4 *>(src);
         const int n4 = npix * (int)dv.q4;
-        for (int i = tid; i < n4; i += nthreads) {
-            const float4 v = src4[i];
-            const int p = (int)(((unsigned)i * dv.magic) >> 20);
-            float *dst = tile + p * ld + (i - p * (int)dv.q4) * 4;
-            dst[0] = v.x;
-            dst[1] = v.y;
-            dst[2] = v.z;
-            dst[3] = v.w;
+        for (int i0 = tid; i0 < n4; i0 += NT * U) {
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT;
+                v[u] = src4[i < n4 ? i : i0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT;
+                if (i < n4) {
+                    const int p = (int)(((unsigned)i * dv.magic) >> 20);
+                    float *dst = tile + p * ld + (i - p * (int)dv.q4) * 4;
+                    dst[0] = v[u].x;
+                    dst[1] = v[u].y;
+                    dst[2] = v[u].z;
+                    dst[3] = v[u].w;
+                }
+            }
         }
     } else {
-        for (int i = tid; i < npix * Kp; i += nthreads) tile[(i / Kp) * ld + (i % Kp)] = src[i];
+        constexpr int U = 8;
+        const int n = npix * Kp;
+        for (int i0 = tid; i0 < n; i0 += NT * U) {
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT;
+                v[u] = src[i < n ? i : i0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * NT;
+                if (i < n) tile[(i / Kp) * ld + (i % Kp)] = v[u];
+            }
+        }
     }
 }
 
@@ -176,7 +208,7 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
     const int tid = threadIdx.x;
     const bool window = win_stats && l3c::use_window(win_stats[b]);   // uniform over the image's blocks
     const float *src = P + (b * HW + pix0) * Kp;
-    fill_tile(tile, src, npix, Kp, ld, dv, tid, 256);
+    fill_tile<256>(tile, src, npix, Kp, ld, dv, tid);
     for (int i = tid; i < Lp; i += 256) s_t[i] = targets[i];
     __syncthreads();
     // The mixture parameters of the 32 pixels, one (pixel, component) item per thread in both phases (round 5; one thread per pixel
@@ -316,7 +348,8 @@ constexpr int kHeadPix = 64;  // == interval block length, so one block writes w
 
 // (Tried: kHeadPix * C threads per block -- one (pixel, channel) item per thread, no idle lanes in the compute phase: 4.4 ->
 // 6.8 ms per launch at batch 128 [PMC]: fewer wavefronts per CU for the LDS-bound tile fill outweigh the busier lanes.)
-__global__ __launch_bounds__(320) void encode_intervals_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
+template <int NT>
+__global__ __launch_bounds__(NT) void encode_intervals_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
                                                                int rgb, int Lp, uint32_t *__restrict__ iv, TileDiv dv) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kHeadPix][Kp + 1]
@@ -328,8 +361,8 @@ __global__ __launch_bounds__(320) void encode_intervals_kernel(const float *__re
     const int npix = (int)((HW - pix0) < kHeadPix ? (HW - pix0) : kHeadPix);
     const int tid = threadIdx.x;
     const float *src = P + (b * HW + pix0) * Kp;
-    const int nthreads = (int)blockDim.x;
-    fill_tile(tile, src, npix, Kp, ld, dv, tid, nthreads);   // (a wavefront per pixel row instead: 4.4 -> 6.8 ms)
+    constexpr int nthreads = NT;
+    fill_tile<NT>(tile, src, npix, Kp, ld, dv, tid);   // (a wavefront per pixel row instead: 4.4 -> 6.8 ms)
     __syncthreads();
     const float scale = (float)(65536 - (Lp - 1));
     const int64_t n_streams = (int64_t)gridDim.y * C;
@@ -565,10 +598,14 @@ int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *t
 #ifdef L3C_IV_THREADS_256
     const int nthreads = 256;
 #else
-    const int nthreads = (kHeadPix * C > 256 && kHeadPix * C <= 320) ? kHeadPix * C : 256;
+    const int nthreads = kHeadPix * C == 320 ? 320 : 256;
 #endif
-    hipLaunchKernelGGL(encode_intervals_kernel, grid, dim3(nthreads), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K,
-                       rgb, Lp, intervals, tile_div(Kp, kHeadPix));
+    if (nthreads == 320)
+        hipLaunchKernelGGL(encode_intervals_kernel<320>, grid, dim3(320), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, Lp,
+                           intervals, tile_div(Kp, kHeadPix));
+    else
+        hipLaunchKernelGGL(encode_intervals_kernel<256>, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, Lp,
+                           intervals, tile_div(Kp, kHeadPix));
     return l3c::check_launch("encode_intervals_kernel");
 }
 

@@ -86,12 +86,21 @@ class PackedConv(object):
         if self.KS == 1 and stride == 1 and self.Cin % 64 == 0 and self.Cout <= 160:
             self.packed_pw = torch.empty(lib.l3c_conv_pw_packed_words(self.Cout, self.Cin), dtype=torch.float32, device='cuda')
             call('l3c_conv_pw_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self.packed_pw), stream())
-        self._packed_poly = self._packed_wino2 = self._zero_bias = None
+        self._packed_poly = self._packed_wino2 = self._zero_bias = self._packed_wino4_shuffle = None
 
     def _pack_wino4(self, w):
         packed = torch.empty(_lib.load().l3c_conv_wino4_packed_words(w.shape[0], w.shape[1]), dtype=torch.float32, device='cuda')
         call('l3c_conv_wino4_pack_weights', ptr(w.contiguous()), w.shape[0], w.shape[1], ptr(packed), stream())
         return packed
+
+    def packed_wino4_shuffle(self):
+        """the 64 -> 256 PixelShuffle tail on the Winograd kernel (include/l3c_hip.h, L3C_EPI_PIXEL_SHUFFLE): G g G^T of the weights in
+        sub-pixel-major order -- row 64 s + oc = the layer's row 4 oc + s -- packed on first use"""
+        if self._packed_wino4_shuffle is None:
+            assert self.Cout == 256
+            w = self.weight.reshape(64, 4, self.Cin, 3, 3).permute(1, 0, 2, 3, 4).reshape(256, self.Cin, 3, 3)
+            self._packed_wino4_shuffle = self._pack_wino4(w)
+        return self._packed_wino4_shuffle
 
     def _phase_kernels(self):
         return [self.weight[:, :, a::2, b::2] for a in (0, 1) for b in (0, 1)]
@@ -144,7 +153,7 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         return t is None or (t.shape[-1] % 4 == 0 and coff % 4 == 0 and t.data_ptr() % 16 == 0)
     in_ok = x.data_ptr() % 16 == 0 and cstride % 4 == 0 and in_coff % 4 == 0 and H * W * cstride * 4 < 0x7ffffff0
     wino_ok = (layer.KS == 3 and layer.stride == 1 and in_ok and _aligned(out, out_coff) and _aligned(residual, res_coff) and
-               layer.Cout % (16 if pixel_shuffle else 4) == 0 and
+               layer.Cout % 4 == 0 and (not pixel_shuffle or layer.Cout == 256) and
                not (pixel_shuffle and (relu or residual is not None or layer.dilation != 1)))
     poly_ok = (layer.packed_poly_fused is not None and H % 2 == 0 and W % 2 == 0 and in_ok and _aligned(out, out_coff) and
                residual is None and not relu and not pixel_shuffle)
@@ -164,7 +173,8 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
         raise _lib.L3CError('convolution outside every MFMA kernel\'s preconditions (Cin % 16 != 0)')
     d = ConvDesc()
     d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
-    d.packed_w = ptr({'wino4': layer.packed_wino4, 'pw': layer.packed_pw, 'gemm': layer.packed, 'direct': layer.weight}[kernel]
+    d.packed_w = ptr({'wino4': layer.packed_wino4_shuffle() if (kernel == 'wino4' and pixel_shuffle) else layer.packed_wino4,
+                      'pw': layer.packed_pw, 'gemm': layer.packed, 'direct': layer.weight}[kernel]
                      if kernel != 'wino2' else layer.packed_wino2())
     d.bias = ptr(layer.bias)
     d.residual = ptr(residual, torch.float32) if residual is not None else None

@@ -12,8 +12,11 @@ from l3c_pytorch_amd import ops  # noqa: E402
 from oracle import cdf as ocdf  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+ONLY = sys.argv[2] if len(sys.argv) > 2 else ''
 g = torch.Generator(device='cuda').manual_seed(0)
 for name, (H, W, C, L, lo, hi, rgb) in (('RGB scale 512x768', (512, 768, 3, 256, 0, 255, True)), ('z scale 256x384', (256, 384, 5, 25, -1, 1, False))):
+    if ONLY and ONLY not in name:
+        continue
     Kp = (4 if rgb else 3) * C * 10
     P = torch.randn(B, H, W, Kp, device='cuda', generator=g)
     if rgb:
