@@ -23,7 +23,7 @@ Prints ONE JSON line (rank 0).  Besides the contract fields it carries (headline
   roofline      dominant kernel = conv_wino4_kernel (Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32): `achieved` = the FLOPs the
                 matrix pipe EXECUTES (36/144 of the direct convolution's) summed over its launches in the timed region / their
                 summed HIP-event durations; `peak` = 157.3 TFLOP/s dense fp32 MFMA at 2.4 GHz; the direct-convolution
-                (algorithmic) rate, the HBM side of the same launches, and -- from profiles/r04_pmc_bench.json, PMC passes over THIS
+                (algorithmic) rate, the HBM side of the same launches, and -- from profiles/r05_pmc_bench.json, PMC passes over THIS
                 script reduced to the launches of its timed steps -- the measured HBM traffic per launch and the counter-based pipe
                 occupancy ride along.  A PMC table whose launch population differs from this run's, or whose bytes are below the
                 compulsory (algorithmic) bytes, is reported as `invalid`, never as `traffic`
@@ -246,7 +246,7 @@ def contract(args, ranks, value, elapsed, **extra):
 # ---- headline: batches of 768x512 ------------------------------------------------------------------------------------------------
 
 
-PMC_TABLE = os.path.join('profiles', 'r04_pmc_bench.json')
+PMC_TABLE = os.path.join('profiles', 'r05_pmc_bench.json')
 
 
 def load_json(rel):
@@ -271,7 +271,7 @@ def csrc_stamp():
 
 
 def load_pmc_table():
-    """profiles/r04_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
+    """profiles/r05_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
     --pmc run of THIS script, reduced by tools/pmc_bench.py and stamped with csrc_stamp() of the sources it was taken on.
     -> (table or None, 'current' | 'stale' | 'absent')."""
     try:

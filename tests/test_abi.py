@@ -79,12 +79,18 @@ def test_argument_validation_of_every_family_precedes_any_launch():
     part = _lib.AcDecodePart(fake, 26, fake, fake, fake, 2, 10, None, fake, fake, 0, fake, 10, 0)
     assert lib.l3c_ac_decode_chunks((_lib.AcDecodePart * 1)(part), 1, None) == -1 and 'must differ' in err()
     assert lib.l3c_ac_decode_chunks((_lib.AcDecodePart * 1)(part), 9, None) == -1 and 'parts per call' in err()
+    # window rows (ABI 3): only for the 256-symbol alphabet, and only with everything a missed row needs
+    assert lib.l3c_dmll_cdf_table(fake, fake, fake, 1, 10, 5, 10, 0, 1, 0, 10, 26, fake, None, fake, None) == -1 and 'window rows' in err()
+    wpart = _lib.AcDecodePart(fake, 257, fake, fake, fake, 2, 10, fake, None, fake, 1, fake, 10, 0)
+    wpart.window_stats_in, wpart.window_stats_out = fake, fake
+    wpart.C, wpart.K, wpart.c, wpart.HW, wpart.pix0 = 3, 10, 0, 100, 0
+    assert lib.l3c_ac_decode_chunks((_lib.AcDecodePart * 1)(wpart), 1, None) == -1 and 'window rows' in err()      # P / targets missing
     assert lib.l3c_ac_decode_state_bytes() == 32
     # mixture head
     assert lib.l3c_dmll_nll(fake, fake, 1, 10, 3, 17, 1, 0.0, 255.0, 256, fake, None) == -1 and 'K out of range' in err()
     assert lib.l3c_dmll_nll(fake, fake, 1, 10, 5, 10, 1, 0.0, 255.0, 256, fake, None) == -1 and 'C == 3' in err()
-    assert lib.l3c_dmll_cdf_table(fake, None, fake, 1, 10, 3, 10, 1, 1, 0, 10, 257, fake, None, None) == -1 and 'decoded so far' in err()
-    assert lib.l3c_dmll_cdf_table(fake, fake, fake, 1, 10, 3, 10, 1, 1, 5, 10, 257, fake, None, None) == -1 and 'outside the image' in err()
+    assert lib.l3c_dmll_cdf_table(fake, None, fake, 1, 10, 3, 10, 1, 1, 0, 10, 257, fake, None, None, None) == -1 and 'decoded so far' in err()
+    assert lib.l3c_dmll_cdf_table(fake, fake, fake, 1, 10, 3, 10, 1, 1, 5, 10, 257, fake, None, None, None) == -1 and 'outside the image' in err()
     assert lib.l3c_dmll_sample(fake, fake, None, 1, 10, 3, 10, 1, fake, None) == -1 and 'null pointer' in err()
     # convolution
     assert lib.l3c_conv_pack_weights(fake, 64, 60, 3, fake, None) == -1 and 'multiple of 8' in err()

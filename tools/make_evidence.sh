@@ -1,5 +1,5 @@
 #!/bin/bash
-# Regenerate every profiles/r04_* evidence file (E) with ONE gpurun call (round-2 verdict: "make the evidence reproducible by command"):
+# Regenerate every profiles/r05_* evidence file (E) with ONE gpurun call (round-2 verdict: "make the evidence reproducible by command"):
 #
 #     /usr/local/graft/bin/gpurun --timeout 2400 -- tools/make_evidence.sh      # on the GPU box: writes gpurun_out/evidence/
 #     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r04_*
@@ -11,7 +11,7 @@
 # profiled process launches exactly (warm-up + steps) identical steps; tools/pmc_bench.py keeps the launches of the timed steps only and
 # stamps the table with the hash of the kernel sources; two more passes over a decode-only command for the decode-side kernels;
 # (5) the other two configs at full size.
-R=r04
+R=r05
 if [ "$1" == "--collect" ]; then
     cd "$(dirname "$0")/.." || exit 1
     E=gpurun_out/evidence
@@ -25,6 +25,11 @@ if [ "$1" == "--collect" ]; then
     cp $E/bench_large.json profiles/${R}_bench_large.json
     cp $E/pytest_headline.log profiles/${R}_pytest_headline.log
     [ -f $E/decode_overlap.log ] && cp $E/decode_overlap.log profiles/${R}_decode_overlap.log
+    [ -f $E/decode_timeline.log ] && cp $E/decode_timeline.log profiles/${R}_decode_timeline.log
+    [ -f $E/decode_kernel_stats.csv ] && cp $E/decode_kernel_stats.csv profiles/${R}_decode_batch128_kernel_stats.csv
+    [ -f $E/parity_truth.json ] && cp $E/parity_truth.json profiles/${R}_parity_truth.json
+    [ -f $E/decode_modes.log ] && cp $E/decode_modes.log profiles/${R}_decode_window_modes.log
+    [ -f $E/pytest_gpu.log ] && cp $E/pytest_gpu.log profiles/${R}_pytest_gpu.log
     ls -la profiles/${R}_*
     exit 0
 fi
@@ -44,6 +49,7 @@ fi
 rm -rf "$E"; mkdir -p "$E"
 LIGHT="--no-cpu-baseline --no-parity --no-extra-legs"
 timeout 900 python -m pytest tests/test_gpu_headline.py -q > $E/pytest_headline.log 2>&1
+timeout 600 python tools/parity_truth.py --out $E/parity_truth.json > $E/parity_truth.log 2>&1      # fp64 ground truth: the three-way table
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $E/smoke.log 2>&1; tail -2 $E/smoke.log
 cp gpurun_out/parity_768x512_*.json $E/
 # (--no-decode also skips the batch-1 latency leg: the profiled process then launches every encode-side kernel warm-up + steps times and nothing else, so the
@@ -59,8 +65,14 @@ timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACT
 # decode side: FETCH / WRITE passes over one batch-128 decode (tools/decode_profile.py), and its kernel trace for the overlap analysis
 timeout 300 rocprofv3 --pmc FETCH_SIZE -d $E/pmcd/fetch -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/pmcd_fetch.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE -d $E/pmcd/write -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/pmcd_write.err
-timeout 300 rocprofv3 --kernel-trace -d $E/dtrace -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/dtrace.err
+timeout 300 rocprofv3 --kernel-trace --stats -d $E/dtrace -o run --output-format csv -- python tools/decode_profile.py 128 > /dev/null 2> $E/dtrace.err
 python tools/decode_overlap.py $E/dtrace > $E/decode_overlap.log
+( cd tools && python decode_timeline.py $E/dtrace > $E/decode_timeline.log )
+find $E/dtrace -name '*kernel_stats.csv' -exec cp {} $E/decode_kernel_stats.csv \;
+# the decode with window rows where the streams allow it (auto: the product), with full rows only (never: the round-4 decoder), both checkpoints
+for ck in calibrated default; do for mode in auto never; do
+  timeout 300 python tools/decode_profile.py 128 $ck $mode 2>&1 | grep "decode_batch B" | head -2 | tr '\n' ' ' | sed "s/^/$ck $mode: /"; echo
+done; done > $E/decode_modes.log
 python tools/pmc_bench.py $E/pmc 128 --steps 2 --warmup 1 --decode-root $E/pmcd > $E/pmc_bench.json
 cp $E/pmc_bench.json profiles/${R}_pmc_bench.json      # (the box's copy: the bench line below then reports it as current)
 timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err

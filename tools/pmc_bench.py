@@ -1,11 +1,11 @@
 #!/usr/bin/env python
-"""Reduce rocprofv3 --pmc passes over `bench.py` to the per-kernel table bench.py reads (profiles/r04_pmc_bench.json).
+"""Reduce rocprofv3 --pmc passes over `bench.py` to the per-kernel table bench.py reads (profiles/r05_pmc_bench.json).
 
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_bench/fetch -o run --output-format csv -- python bench.py --steps 2 --warmup 1 --no-decode ...
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_bench/write ...
     rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA \
               -d gpurun_out/pmc_bench/sq ...
-    python tools/pmc_bench.py gpurun_out/pmc_bench BATCH [--steps 2] [--decode-root gpurun_out/pmc_decode] > profiles/r04_pmc_bench.json
+    python tools/pmc_bench.py gpurun_out/pmc_bench BATCH [--steps 2] [--decode-root gpurun_out/pmc_decode] > profiles/r05_pmc_bench.json
 
 ONLY the launches of bench.py's timed region are reduced (round-3 verdict: the round-3 table averaged warm-up, timed steps AND the
 decode leg's batch-128 / batch-1 launches, so its per-launch bytes were not comparable with the algorithmic bytes of the timed
