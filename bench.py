@@ -49,7 +49,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
-import l3c_pytorch_amd  # noqa: E402,F401  (before the first HIP call: the package configures the runtime's hardware queues, helpers/runtime.py)
+import l3c_pytorch_amd  # noqa: E402,F401
 
 H, W = 512, 768
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense, 2.4 GHz
@@ -811,7 +811,7 @@ def main(argv=None):
             raise SystemExit(rc)
         return None
     if args.config == 'dataset':
-        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')   # several small forward passes side by side, see Bitcoding.encode_many
+        l3c_pytorch_amd.configure_hip_queues()            # several small forward passes side by side, see Bitcoding.encode_many (before HIP starts)
     ranks = Ranks(stub=args.stub_step)
     if args.gpus != ranks.world:
         raise SystemExit('bench.py: --gpus {} but the launcher started {} rank(s) (WORLD_SIZE)'.format(args.gpus, ranks.world))

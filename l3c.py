@@ -13,6 +13,8 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import l3c_pytorch_amd  # noqa: E402,F401
+
+l3c_pytorch_amd.configure_hip_queues()      # image sets / auto-crops run several forward passes side by side (before the first HIP call)
 from l3c_pytorch_amd import torchac  # noqa: E402
 from l3c_pytorch_amd.test.multiscale_tester import DecodeError, EncodeError, MultiscaleTester  # noqa: E402
 

@@ -317,13 +317,15 @@ def test_forward_streams_follow_the_hardware_queues(monkeypatch):
     assert runtime.forward_streams_allowed(1) == 1
 
 
-def test_the_package_configures_the_queues_on_import():
-    """import l3c_pytorch_amd before HIP starts -> GPU_MAX_HW_QUEUES is set (8) unless the caller chose a value (a fresh interpreter)."""
+def test_configure_hip_queues_is_an_explicit_call():
+    """`l3c_pytorch_amd.configure_hip_queues()` before HIP starts -> GPU_MAX_HW_QUEUES = 8 unless the caller chose a value; importing
+    the package alone leaves the runtime's default (batches of equally sized images are faster with it) -- fresh interpreters."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = 'import os, sys; sys.path.insert(0, {!r}); import l3c_pytorch_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"))'.format(root)
+    code = ('import os, sys; sys.path.insert(0, {!r}); import l3c_pytorch_amd; a = os.environ.get("GPU_MAX_HW_QUEUES"); '
+            'l3c_pytorch_amd.configure_hip_queues(); print(a, os.environ.get("GPU_MAX_HW_QUEUES"))').format(root)
     env = {k: v for k, v in os.environ.items() if k != 'GPU_MAX_HW_QUEUES'}
-    assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().strip() == '8'
+    assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().split() == ['None', '8']
     env['GPU_MAX_HW_QUEUES'] = '2'
-    assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().strip() == '2'
+    assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().split() == ['2', '2']
