@@ -811,7 +811,8 @@ def main(argv=None):
             raise SystemExit(rc)
         return None
     if args.config == 'dataset':
-        l3c_pytorch_amd.configure_hip_queues()            # several small forward passes side by side, see Bitcoding.encode_many (before HIP starts)
+        from l3c_pytorch_amd.helpers import runtime as _runtime
+        _runtime.configure_hip_queues()                   # several small forward passes side by side, see Bitcoding.encode_many (before HIP starts)
     ranks = Ranks(stub=args.stub_step)
     if args.gpus != ranks.world:
         raise SystemExit('bench.py: --gpus {} but the launcher started {} rank(s) (WORLD_SIZE)'.format(args.gpus, ranks.world))
