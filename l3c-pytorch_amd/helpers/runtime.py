@@ -120,8 +120,13 @@ def plan_affinity(rank_in_node, ranks_on_node, device_index, allowed=None, sysfs
     node = gpu_numa_node(device_index, sysfs)
     if node is not None:
         cpus = sorted(node_cpus(node, sysfs) & set(allowed))
+        # the local ranks whose GPUs hang off the same node (local rank r drives device r) split its CPUs evenly
+        peers = [r for r in range(ranks_on_node) if (r == rank_in_node or gpu_numa_node(r, sysfs) == node)]
+        if cpus and len(peers) > 1 and len(cpus) >= len(peers):
+            per, k = len(cpus) // len(peers), peers.index(rank_in_node)
+            cpus = cpus[k * per:(k + 1) * per]
         if cpus:
-            return {'cpus': cpus, 'numa_node': node, 'source': 'sysfs numa_node of the GPU'}
+            return {'cpus': cpus, 'numa_node': node, 'source': 'sysfs numa_node of the GPU' + (' (1/{} of the node)'.format(len(peers)) if len(peers) > 1 else '')}
     if ranks_on_node > 1 and len(allowed) >= ranks_on_node:
         per = len(allowed) // ranks_on_node
         return {'cpus': allowed[rank_in_node * per:(rank_in_node + 1) * per], 'numa_node': node, 'source': 'even slice of the allowed CPUs (no NUMA information)'}

@@ -295,6 +295,13 @@ def test_numa_plan_from_a_fake_sysfs(tmp_path):
     p0 = runtime.plan_affinity(0, 2, 0, allowed=allowed, sysfs=str(sysfs))
     p1 = runtime.plan_affinity(1, 2, 1, allowed=allowed, sysfs=str(sysfs))
     assert p0['numa_node'] == 0 and p0['cpus'] == [0, 1, 2, 3] and p1['numa_node'] == 1 and p1['cpus'] == [4, 5, 6, 7]
+    # two local ranks whose GPUs share a node split its CPUs
+    d = sysfs / 'class' / 'drm' / 'card2' / 'device'
+    d.mkdir(parents=True)
+    (d / 'numa_node').write_text('1\n')
+    s1 = runtime.plan_affinity(1, 3, 1, allowed=allowed, sysfs=str(sysfs))
+    s2 = runtime.plan_affinity(2, 3, 2, allowed=allowed, sysfs=str(sysfs))
+    assert s1['cpus'] == [4, 5] and s2['cpus'] == [6, 7] and runtime.plan_affinity(0, 3, 0, allowed=allowed, sysfs=str(sysfs))['cpus'] == [0, 1, 2, 3]
     # a device sysfs knows nothing about: an even slice per rank (disjoint), or nothing for a single rank
     q = [runtime.plan_affinity(r, 4, 5 + r, allowed=allowed, sysfs=str(sysfs)) for r in range(4)]
     assert [x['cpus'] for x in q] == [[0, 1], [2, 3], [4, 5], [6, 7]] and all(x['numa_node'] is None for x in q)
