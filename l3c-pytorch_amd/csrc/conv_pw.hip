@@ -51,8 +51,13 @@ __device__ __forceinline__ int xcd_remap_pw(int bid, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
 }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64, 3) void conv_pw_kernel(const PwParams p) {
+// X5 (round 5; NW == 4 only): 128 < Cout <= 160 on FOUR wavefronts -- wavefront nj owns channel group nj for all 128 pixels AND the fifth
+// group (channels 128 .. 159) for pixel fragment nj: 80 instead of 64 MFMAs per chunk, the same for every wavefront, two blocks per CU
+// (176 registers) = two wavefronts on every SIMD.  The five-wavefront form (NW == 5) puts ten wavefronts of two blocks on four SIMDs
+// (3, 3, 2, 2): 83 % at best.  Same products in the same order per output: bit-identical.
+template <int NW, bool X5 = false>
+__global__ __launch_bounds__(NW * 64, X5 ? 2 : 3) void conv_pw_kernel(const PwParams p) {
+    static_assert(!X5 || NW == 4, "the split fifth group: four wavefronts");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int T = NW * 64;
     constexpr int N_PIECES = PW_TM * (PW_CK / 4);            // 16-byte pieces of a chunk of a tile: 1024
@@ -111,9 +116,11 @@ __global__ __launch_bounds__(NW * 64, 3) void conv_pw_kernel(const PwParams p) {
     const int n_groups_o = (p.Cout + 31) / 32;
     const auto w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, n_cc * 4 * n_groups_o * 256 * 4, 0x00020000);
     const int w_lane = (nj * 256 + lane * 4) * 4;
-    f32x4 bq[4];
+    f32x4 bq[4], bx[4];   // bx: the fifth channel group's weights (X5)
     auto fetch_b = [&](int cc, int g) {
         bq[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, w_lane, ((cc * 4 + g) * n_groups_o) * 1024, 0));
+        if constexpr (X5)
+            bx[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (4 * 256 + lane * 4) * 4, ((cc * 4 + g) * n_groups_o) * 1024, 0));
     };
 
     // prologue: chunks 0 and 1 of the first tile
@@ -126,12 +133,13 @@ __global__ __launch_bounds__(NW * 64, 3) void conv_pw_kernel(const PwParams p) {
     for (int g = 0; g < 4; ++g) fetch_b(0, g);
     __syncthreads();
     const int a_lane = lx * PW_PS + half * 4;                  // A fragment of pixel (32 m + lx): channels 8 g + 4 half .. + 3
-    f32x4 af[2][4];
+    f32x4 af[2][4], afx[2];   // afx (X5): pixel fragment nj once more, for the fifth channel group (a second LDS read instead of 48 selects per chunk)
 #pragma unroll
     for (int m = 0; m < 4; ++m) af[0][m] = *reinterpret_cast<const f32x4 *>(lds + a_lane + m * 32 * PW_PS);
+    if constexpr (X5) afx[0] = *reinterpret_cast<const f32x4 *>(lds + a_lane + nj * 32 * PW_PS);
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the loop head is also reached from its own back edge (see conv_wino.hip)
 
-    f32x16 acc[4];
+    f32x16 acc[4], accx;
     // One chunk: 4 groups of 8 input channels x 4 pixel fragments x 4 k-steps = 64 MFMAs.  Invariants at its start: buffer
     // par holds chunk c; af[0] = the A fragments of its group 0; bq = its weights (in flight); `stage` = chunk c + 1 (in flight);
     // the prefetch pointer is at chunk c + 2.
@@ -151,10 +159,18 @@ __global__ __launch_bounds__(NW * 64, 3) void conv_pw_kernel(const PwParams p) {
                 __syncthreads();
 #pragma unroll
                 for (int m = 0; m < 4; ++m) af[nb][m] = *reinterpret_cast<const f32x4 *>(a_nxt + m * 32 * PW_PS);
+                if constexpr (X5) afx[nb] = *reinterpret_cast<const f32x4 *>(a_nxt + nj * 32 * PW_PS);
             }
             const f32x4 B = bq[g];
+            const f32x4 BX = bx[g];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
+                if constexpr (X5) {   // pixel fragment nj x the fifth channel group
+                    __builtin_amdgcn_sched_barrier(0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(afx[cb][t], BX[t], (FIRST && g == 0 && t == 0) ? zero16 : accx, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (t == 0 && g < 3) afx[nb] = *reinterpret_cast<const f32x4 *>(a_cur + nj * 32 * PW_PS + (g + 1) * 8);
+                }
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     __builtin_amdgcn_sched_barrier(0);
@@ -198,6 +214,17 @@ __global__ __launch_bounds__(NW * 64, 3) void conv_pw_kernel(const PwParams p) {
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[m][r] + bias_v), o_rsrc,
                                                       o_lane + pix * ocs4, 0, 0);
             }
+        if constexpr (X5) {   // the fifth group's fragment of this wavefront: pixels 32 nj + ..., channels 128 + lx
+            const int nx = 128 + lx;
+            const bool okx = nx < p.Cout;
+            const float bias_x = okx ? p.bias[nx] : 0.0f;
+            const int ox_lane = okx ? (4 * half * p.out_cstride + nx) * 4 : 0x7ffffff0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pix = 32 * nj + (r & 3) + 8 * (r >> 2);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, accx[r] + bias_x), o_rsrc, ox_lane + pix * ocs4, 0, 0);
+            }
+        }
     }
 }
 
@@ -262,7 +289,11 @@ int l3c_conv_pw(const l3c_conv_desc *d, l3c_stream_t stream) {
     if (d->Cout <= 128) {
         hipLaunchKernelGGL(conv_pw_kernel<4>, dim3((unsigned)p.total_blocks), dim3(256), PW_LDS_BYTES, l3c::as_stream(stream), p);
     } else {
+#ifdef L3C_PW_FIVE_WAVES
         hipLaunchKernelGGL(conv_pw_kernel<5>, dim3((unsigned)p.total_blocks), dim3(320), PW_LDS_BYTES, l3c::as_stream(stream), p);
+#else
+        hipLaunchKernelGGL((conv_pw_kernel<4, true>), dim3((unsigned)p.total_blocks), dim3(256), PW_LDS_BYTES, l3c::as_stream(stream), p);
+#endif
     }
     return l3c::check_launch("conv_pw_kernel");
 }

@@ -24,7 +24,8 @@ BUDGET = {
                        ('conv_wino4_kernelILb0ELb1ELb0', 256, 0),      # residual
                        ('conv_wino4_kernelILb0ELb0ELb1', 256, 0)],     # PixelShuffle tail
     'conv_wino.hip': [('conv_wino_kernel', 256, 0)],
-    'conv_pw.hip': [('conv_pw_kernel', 168, 0)],                       # three blocks of four waves per CU
+    'conv_pw.hip': [('conv_pw_kernelILi4ELb0', 168, 0),                # three blocks of four waves per CU
+                    ('conv_pw_kernelILi4ELb1', 256, 0)],               # the split-fifth-group form (128 < Cout <= 160): two blocks per CU
     'ac_kernels.hip': [('ac_decode_ring_kernel', 256, 0), ('ac_decode_lean_kernel', 256, 0)],
 }
 
