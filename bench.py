@@ -447,12 +447,17 @@ def decode_leg(bc, enc, imgs, compute_stream):
     SYMBOLS_PER_PX = 4.640625           # 3 P0 + 5 (P1 + P2 + P3) symbols per image pixel, SURVEY.md section 8d
     with torch.cuda.stream(compute_stream):
         files = enc.to_bytes()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dec, _ = bc.decode_batch(files)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        lossless = bool(torch.equal(dec.to(torch.uint8), imgs.to(torch.uint8)))
+        # the first call of the process also pays the allocator's first touch and the code objects' load: reported, not the figure
+        times, lossless = [], True
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dec, _ = bc.decode_batch(files)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+            lossless = lossless and bool(torch.equal(dec.to(torch.uint8), imgs.to(torch.uint8)))
+            del dec
+        dt_first, dt = times[0], sorted(times[1:])[1]
         bc.decode_batch(files[:1])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -462,11 +467,12 @@ def decode_leg(bc, enc, imgs, compute_stream):
         lossless = lossless and bool(torch.equal(dec1.to(torch.uint8), imgs[:1].to(torch.uint8)))
     B = len(files)
     return {'value': round(B * H * W / 1e6 / dt, 3), 'unit': 'MPix/s', 'batch': B, 'seconds': round(dt, 3),
-            'lossless': lossless, 'msym_per_s_aggregate': round(B * H * W * SYMBOLS_PER_PX / 1e6 / dt, 1),
+            'seconds_all_calls': [round(t, 3) for t in times], 'first_call_seconds': round(dt_first, 3),
+            'timing': 'median of three calls after the first one of the process', 'lossless': lossless, 'msym_per_s_aggregate': round(B * H * W * SYMBOLS_PER_PX / 1e6 / dt, 1),
             'longest_chain_symbols': H * W, 'batch1_seconds': round(dt1, 4), 'batch1_mpix_per_s': round(H * W / 1e6 / dt1, 3),
-            'batch1_ns_per_symbol_upper_bound': round(dt1 / (H * W) * 1e9 / 1.125, 1),
+            'batch1_ns_per_symbol_upper_bound': round(dt1 / (H * W) * 1e9 / 1.0625, 1),
             'note': 'host .l3c bytes -> pixels in HBM; latency-bound: serial chains of {} symbols per RGB channel, the three '
-                    'channels pipelined a chunk of pixels apart (18 chunk steps for 16 chunks: x 1.125); the upper bound charges the whole '
+                    'channels pipelined a chunk of pixels apart (34 chunk steps for 32 chunks: x 1.0625, two 1024-symbol probe chunks in front); the upper bound charges the whole '
                     'one-image decode -- get_P convolutions, bottleneck scales, tables -- to the RGB chain'.format(H * W)}
 
 
@@ -491,7 +497,7 @@ def latency_leg(bp, bc, img1, compute_stream, reps=5):
         lossless = bool(torch.equal(dec.to(torch.uint8), img1.to(torch.uint8)))
     e, d = statistics.median(enc_s), statistics.median(dec_s)
     return {'image': '768x512', 'encode_seconds': round(e, 5), 'decode_seconds': round(d, 5), 'encode_mpix_per_s': round(H * W / 1e6 / e, 2),
-            'decode_mpix_per_s': round(H * W / 1e6 / d, 2), 'decode_ns_per_symbol_upper_bound': round(d / (H * W) * 1e9 / 1.125, 1),
+            'decode_mpix_per_s': round(H * W / 1e6 / d, 2), 'decode_ns_per_symbol_upper_bound': round(d / (H * W) * 1e9 / 1.0625, 1),
             'file_bytes': len(data[0]), 'lossless': lossless, 'reps': reps,
             'note': 'one image: image in HBM -> .l3c bytes on the host -> pixels in HBM (median); the serial interval recurrence of the '
                     'three 393 216-symbol RGB streams sets the encode time, the symbol-by-symbol decode chains the decode time'}
