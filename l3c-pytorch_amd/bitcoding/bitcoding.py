@@ -553,6 +553,8 @@ class Bitcoding(object):
     RGB_CHUNKS = 32          # chunks per RGB channel for batches of 16 images and more (round 5, with window rows: 32 instead of 16 --
     #                          the row form of a chunk follows the stream's misses two chunks earlier, and shorter chunks follow faster:
     #                          batch of 128 0.379 -> 0.365 s, the default-init checkpoint 0.585 -> 0.55 s)
+    #                          64 / 96 chunks: another 1.3 / 1.7 % (0.3545 -> 0.350 / 0.3485 s) for two / three times the launches; not taken:
+    #                          the host already needs 0.24 s of the 0.35 s to issue them [profiles/r05_decode_chunks_probe.log]
     RGB_CHUNKS_FEW = 32      # ... for a few images: the pipeline's fill (two extra chunk steps) weighs more than a step's launches
 
     def _decode_rgb_pipelined(self, P, targets, payloads, B, C, K, H, W):
