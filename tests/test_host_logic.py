@@ -336,3 +336,33 @@ def test_configure_hip_queues_is_an_explicit_call():
     assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().split() == ['None', '8']
     env['GPU_MAX_HW_QUEUES'] = '2'
     assert subprocess.run([sys.executable, '-c', code], env=env, stdout=subprocess.PIPE).stdout.decode().split() == ['2', '2']
+
+
+def test_pmc_table_is_accepted_per_kernel_source(tmp_path, monkeypatch):
+    """bench.load_pmc_table: counters are reported only for kernels whose sources are byte-identical to those the rocprofv3 --pmc passes ran on.
+    A table taken on exactly today's sources is current; one taken before a source WITHOUT roofline kernels changed stays current and says what
+    changed; one taken before a roofline kernel's source changed is stale; a table without per-file stamps falls back to the combined stamp."""
+    import json
+    import bench
+    now = bench.csrc_file_stamps()
+    assert set(bench.ROOFLINE_KERNEL_SOURCES) <= set(now)
+    path = tmp_path / 'pmc.json'
+    monkeypatch.setattr(bench, 'PMC_TABLE', str(path))
+
+    def state_of(table):
+        path.write_text(json.dumps(table))
+        t, state = bench.load_pmc_table()
+        return state, (t or {}).get('_changed_since')
+
+    assert state_of({'csrc_stamp': bench.csrc_stamp(), 'csrc_files': now}) == ('current', None)
+    other = dict(now, **{'conv_small.hip': '0' * 16})
+    assert state_of({'csrc_stamp': 'x', 'csrc_files': other}) == ('current', ['conv_small.hip'])
+    for f in bench.ROOFLINE_KERNEL_SOURCES:
+        assert state_of({'csrc_stamp': 'x', 'csrc_files': dict(now, **{f: '0' * 16})})[0] == 'stale', f
+    assert state_of({'csrc_stamp': 'x'})[0] == 'stale'
+    path.unlink()
+    assert bench.load_pmc_table() == (None, 'absent')
+    # the committed table of this round must be usable by the line the driver runs
+    monkeypatch.undo()
+    t, state = bench.load_pmc_table()
+    assert state == 'current', 'profiles/{} was taken on other sources of the roofline kernels: regenerate it (tools/make_evidence.sh)'.format(bench.PMC_TABLE)

@@ -126,7 +126,7 @@ def main():
     import bench
     out = {'batch': a.batch, 'steps': a.steps, 'warmup': a.warmup,
            'source': 'rocprofv3 --pmc passes over bench.py --no-decode (tools/pmc_bench.py): the launches of the timed region only',
-           'csrc_stamp': bench.csrc_stamp(), 'kernels': {}, 'decode_kernels': {}}
+           'csrc_stamp': bench.csrc_stamp(), 'csrc_files': bench.csrc_file_stamps(), 'kernels': {}, 'decode_kernels': {}}
     for k, c in read_rows(a.root).items():
         if k in DECODE_KEYS:
             continue
