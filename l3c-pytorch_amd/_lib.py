@@ -119,6 +119,7 @@ def load():
     """The shared library, with prototypes installed.  Raises L3CError when it has not been built."""
     global _lib
     if _lib is None:
+        _snapshot_queues()
         if not os.path.isfile(LIB_PATH):
             raise L3CError('libl3c_hip.so not found at {} -- build it with `python l3c-pytorch_amd/csrc/build.py` '
                            '(or __graft_entry__.build()); there is no CPU fallback.'.format(LIB_PATH))
@@ -163,7 +164,14 @@ def call(name, *args):
     check(getattr(load(), name)(*args))
 
 
+def _snapshot_queues():
+    # the package's first HIP touch: remember what GPU_MAX_HW_QUEUES said when the runtime (may have) started -- helpers/runtime.py
+    from .helpers import runtime
+    runtime.snapshot_hw_queues()
+
+
 def require_gpu():
+    _snapshot_queues()
     if not torch.cuda.is_available():
         raise L3CError('no HIP device visible: the l3c-pytorch_amd compute path runs on the GPU only (no CPU fallback)')
 

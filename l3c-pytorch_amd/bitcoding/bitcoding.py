@@ -124,12 +124,22 @@ class EncodedBatch(object):
         overhead = 8 + sum(5 + 4 * C + 4 for C, _, _, _, _ in self.scales)
         return self.total_payload_bytes() + overhead
 
+    @staticmethod
+    def _checked_nbytes(n):
+        """Host-side stream lengths (numpy) -> the same, or L3CError when a stream reported L3C_AC_OVERRUN (int32 -1: its intervals
+        violated c_high > c_low, i.e. table rows not strictly increasing).  The ONE place that turns the device-side marker into an
+        error: `payloads`, `many_to_host_buffer` (through the file sizes) and therefore every file writer go through it."""
+        if (np.asarray(n) < 0).any():
+            from .. import _lib
+            raise _lib.L3CError('range coder overrun: a stream asked for more than 16 bits per symbol (table rows not strictly increasing)')
+        return n
+
     def payloads(self):
         """list over scales (coarse -> fine) of [B][C] bytes objects (one D2H copy per scale)."""
         self.wait()
         res = []
         for C, H, W, out, nbytes in self.scales:
-            n = nbytes.cpu().numpy()
+            n = self._checked_nbytes(nbytes.cpu().numpy())
             host = out[:, :int(n.max())].cpu().numpy()
             res.append([[host[b * C + c, :n[b * C + c]].tobytes() for c in range(C)] for b in range(self.B)])
         return res
@@ -165,10 +175,8 @@ class EncodedBatch(object):
             e.wait()
         sizes = torch.cat([e.file_sizes() for e in encs])
         offs = torch.cumsum(sizes, 0) - sizes
-        sizes_h = sizes.cpu().numpy().astype(np.int64)          # the synchronisation: how many bytes there are
-        if (sizes_h < 0).any():     # a stream reported L3C_AC_OVERRUN (int32 -1): its intervals violated c_high > c_low
-            from .. import _lib
-            raise _lib.L3CError('range coder overrun: a stream asked for more than 16 bits per symbol (table rows not strictly increasing)')
+        # the synchronisation: how many bytes there are (an overrun stream makes its file's size hugely negative: total_payload_bytes)
+        sizes_h = EncodedBatch._checked_nbytes(sizes.cpu().numpy().astype(np.int64))
         total = int(sizes_h.sum())
         dst = torch.empty(total, dtype=torch.uint8, device='cuda')
         first = 0
@@ -212,7 +220,8 @@ class Bitcoding(object):
                  coder_streams=4, forward_streams=3, decode_overlap=None, rgb_window='auto'):
         """coder_streams: side streams the range-coder launches rotate over; forward_streams: streams `encode_many` spreads the forward
         passes of a heterogeneous set over (used when the HIP runtime runs with >= 8 hardware queues -- helpers/runtime.py; the package
-        asks for them on import -- else one, with a warning); decode_overlap: None = the chunk-pipelined RGB decode overlaps its table
+        does NOT ask for them on import: applications that code image sets call l3c_pytorch_amd.configure_hip_queues() before their
+        first HIP call -- else one, with a warning); decode_overlap: None = the chunk-pipelined RGB decode overlaps its table
         and decoder launches from 16 images on, True / False force either; rgb_window: 'auto' = the RGB decoder builds 64-entry table
         rows around the mixture mean where the previous chunks of the stream say that pays, 'always' / 'never' force either form
         (_decode_rgb_pipelined).  None of these changes a bit of a file or of a decoded image.

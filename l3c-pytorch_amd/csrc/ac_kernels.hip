@@ -1214,11 +1214,11 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
 // M0 through s_set_gpr_idx -- so it is tied to this target: any other one must not build it silently.  tools/check_asm_prefetch.py and
 // tools/check_registers.py inspect the compiled kernel at build time; -DL3C_DECODE_ASM_LOOP=0 builds the decoder with the
 // compiler-generated symbol (lean_symbol) everywhere, bit-identical and ~1.7x slower per symbol, as the fallback.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
-#error "ac_decode_lean_kernel's hand-written loop is written for gfx950 (physical SGPR / VGPR numbers); build with -DL3C_DECODE_ASM_LOOP=0 elsewhere"
-#endif
 #ifndef L3C_DECODE_ASM_LOOP
 #define L3C_DECODE_ASM_LOOP 1
+#endif
+#if L3C_DECODE_ASM_LOOP && defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "ac_decode_lean_kernel's hand-written loop is written for gfx950 (physical SGPR / VGPR numbers); build with -DL3C_DECODE_ASM_LOOP=0 elsewhere"
 #endif
 #define L3C_ROW_READS(R0, R1, R2, R3, ADDR)                                                                        \
     "ds_read_u16_d16_hi " R0 ", " ADDR "\n\tds_read_u16_d16_hi " R1 ", " ADDR " offset:128\n\t"                     \
@@ -1319,6 +1319,7 @@ __device__ __forceinline__ void lean_symbol(const RowHi<NJ> &row, const ValidLan
     "s_cmp_eq_u32 %[t0], 0\n\ts_cbranch_scc1 " BACK "\n\t"                                                          \
     "s_mov_b32 %[hit], " N "\n\ts_waitcnt lgkmcnt(0)\n\ts_branch 9f\n"
 
+#if L3C_DECODE_ASM_LOOP   // (the functions below name physical registers: not even parsed for the compiled-symbol fallback build)
 __device__ __forceinline__ void lean_block_uniform(LeanState &st, uint32_t &wrel, uint32_t &minspan, uint32_t value);
 
 // rows j0 (even; set A holds it, wA lane 0 its entry 64) .. R - 1 of a block of window rows; returns with hit != 0 and j at the pair of
@@ -1425,6 +1426,7 @@ __device__ __forceinline__ void lean_block_asm(RowHi<4> &A, RowHi<4> &B, const V
         : "v96", "v97", "v98", "v99", "v100", L3C_BLOCK_CLOBBERS);
     lean_block_uniform(st, wrel, minspan, value);
 }
+#endif   // L3C_DECODE_ASM_LOOP
 
 // WINDOW (round 5): the instantiation for streams whose rows of this chunk are 65-entry window rows -- one row register, the bottleneck
 // scales' loop.  The hand-written loop runs a block as if no symbol could miss; afterwards every lane compares ITS row's rank with its
@@ -1598,6 +1600,7 @@ __device__ __forceinline__ void lean_decode_body(const DecodeArgs &a, uint8_t *r
         uint32_t x = 0;
         const bool full_block = k + 1u < n_blocks;   // a full block that does not hold the stream's last symbol
         bool done = false;
+#if L3C_DECODE_ASM_LOOP
         if constexpr (L3C_DECODE_ASM_LOOP && (NJ == 1 || ALLVALID)) {
             // the hand-written loop, unless the bit window could run out inside the block (a symbol takes at most one word)
             if (full_block) {
@@ -1611,6 +1614,7 @@ __device__ __forceinline__ void lean_decode_body(const DecodeArgs &a, uint8_t *r
                     wrel -= 32u;
                 }
                 const LeanState saved = st;
+                const uint32_t saved_misses = misses;   // (a block that is decoded again must not count its misses twice)
                 uint32_t minspan = 0xFFFFFFFFu;
                 if constexpr (WINDOW) {
                     // rows in pairs through the hand-written loop; it leaves at a MISS (hit = 1 / 2: first / second row of pair j), with the
@@ -1665,11 +1669,13 @@ __device__ __forceinline__ void lean_decode_body(const DecodeArgs &a, uint8_t *r
                 }
                 if (__builtin_expect(!done, 0)) {   // a symbol met the whole 32-bit range or a bad value: again, the careful way
                     st = saved;
+                    misses = saved_misses;
                     row_hi_issue(block_addr(k), rowA);
                     row_hi_wait(rowA);
                 }
             }
         }
+#endif
         if (done) {
         } else if (full_block) {   // rows in pairs, A then B
             for (uint32_t j = 0; j < R; j += 2u) {

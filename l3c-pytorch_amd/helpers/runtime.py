@@ -22,26 +22,45 @@ _WANTED_QUEUES = 8
 _warned = [False]
 
 
+_SNAPSHOT = [None]     # GPU_MAX_HW_QUEUES as it was when this package first touched HIP (the runtime reads it once, at start-up)
+
+
+def snapshot_hw_queues():
+    """Called at the package's first HIP touch (_lib.load / require_gpu / the first stream lookup): from here on `hw_queues()` answers
+    with what the environment said THEN -- a later change of the variable cannot reach the running runtime."""
+    if _SNAPSHOT[0] is None:
+        _SNAPSHOT[0] = _env_queues()
+    return _SNAPSHOT[0]
+
+
+def _env_queues():
+    try:
+        return int(os.environ.get('GPU_MAX_HW_QUEUES', '') or 4)
+    except ValueError:
+        return 4
+
+
 def configure_hip_queues(n=_WANTED_QUEUES):
     """Before HIP start-up: ask the runtime for `n` hardware queues unless the caller has set GPU_MAX_HW_QUEUES.  -> the value in
-    effect for a runtime that starts now (None: HIP is already running, nothing was changed)."""
+    effect for a runtime that starts now; None (with a warning, and WITHOUT touching the environment) when HIP is already running --
+    started by torch (`torch.cuda.is_initialized()`) or by this package's own first HIP touch (`snapshot_hw_queues`, which also covers a
+    runtime that `torch.cuda.is_available()` / `device_count()` or another library started behind torch's flag)."""
     import torch
-    if os.environ.get('GPU_MAX_HW_QUEUES'):
-        return int(os.environ['GPU_MAX_HW_QUEUES'])
+    if os.environ.get('GPU_MAX_HW_QUEUES') and (_SNAPSHOT[0] is None or _SNAPSHOT[0] == _env_queues()):
+        return _env_queues()         # the caller's choice, in effect (or about to be)
     # (torch.cuda.is_initialized() is a flag of torch's own; torch.cuda.is_available() would ASK the runtime for its device count and thereby
     # start it -- with the default four queues -- right before the variable is set: measured, config 4 fell from 158 to 138 MPix/s)
-    if torch.cuda.is_initialized():
+    if torch.cuda.is_initialized() or _SNAPSHOT[0] is not None:
+        warnings.warn('l3c_pytorch_amd.configure_hip_queues(): HIP is already running with GPU_MAX_HW_QUEUES={}; call it before the first '
+                      'HIP call (nothing was changed)'.format(hw_queues()), RuntimeWarning, stacklevel=2)
         return None
     os.environ['GPU_MAX_HW_QUEUES'] = str(n)
     return n
 
 
 def hw_queues():
-    """Hardware queues the HIP runtime of this process was (or will be) started with."""
-    try:
-        return int(os.environ.get('GPU_MAX_HW_QUEUES', '') or 4)
-    except ValueError:
-        return 4
+    """Hardware queues the HIP runtime of this process was (or, before the first HIP touch, will be) started with."""
+    return _SNAPSHOT[0] if _SNAPSHOT[0] is not None else _env_queues()
 
 
 def forward_streams_allowed(wanted):

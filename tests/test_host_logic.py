@@ -313,6 +313,7 @@ def test_forward_streams_follow_the_hardware_queues(monkeypatch):
     """encode_many's side-by-side forward streams need >= 8 hardware queues; with fewer it uses one stream and says so ONCE."""
     import warnings
     from l3c_pytorch_amd.helpers import runtime
+    monkeypatch.setattr(runtime, '_SNAPSHOT', [None])
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')
     assert runtime.hw_queues() == 8 and runtime.forward_streams_allowed(3) == 3
     monkeypatch.setenv('GPU_MAX_HW_QUEUES', '4')
@@ -322,6 +323,24 @@ def test_forward_streams_follow_the_hardware_queues(monkeypatch):
         assert runtime.forward_streams_allowed(3) == 1 and runtime.forward_streams_allowed(3) == 1
     assert len([x for x in w if 'GPU_MAX_HW_QUEUES' in str(x.message)]) == 1
     assert runtime.forward_streams_allowed(1) == 1
+
+
+def test_hw_queues_are_what_the_runtime_started_with(monkeypatch):
+    """Once the package has touched HIP (`snapshot_hw_queues`: _lib.load / require_gpu), a later change of GPU_MAX_HW_QUEUES cannot reach the
+    runtime: `hw_queues()` keeps answering with the value of THEN, `configure_hip_queues()` returns None, warns and leaves the environment alone
+    -- so encode_many never runs three forward streams on four queues silently (advisor, round 5)."""
+    import warnings
+    from l3c_pytorch_amd.helpers import runtime
+    monkeypatch.setattr(runtime, '_SNAPSHOT', [None])
+    monkeypatch.setattr(runtime, '_warned', [False])
+    monkeypatch.delenv('GPU_MAX_HW_QUEUES', raising=False)
+    assert runtime.snapshot_hw_queues() == 4            # HIP "started" with the default
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert runtime.configure_hip_queues() is None and 'GPU_MAX_HW_QUEUES' not in os.environ
+        monkeypatch.setenv('GPU_MAX_HW_QUEUES', '8')    # too late
+        assert runtime.hw_queues() == 4 and runtime.forward_streams_allowed(3) == 1
+    assert any('already running' in str(x.message) for x in w)
 
 
 def test_configure_hip_queues_is_an_explicit_call():
