@@ -29,13 +29,26 @@ extern "C" {
 #define L3C_ERR_HIP (-2)
 #define L3C_ERR_UNSUPPORTED (-3)
 
-#define L3C_ABI_VERSION 3
+#define L3C_ABI_VERSION 4
 
 typedef void *l3c_stream_t;
 
 /* ---- library ------------------------------------------------------------------------------------------------------ */
 
 int l3c_abi_version(void);
+/*
+ * Generation of the BITSTREAM this build reads and writes.  The `.l3c` container has no version field (reference:
+ * src/bitcoding/bitcoding.py:326-375) and the format is only decodable by a decoder whose kernels reproduce the encoder's P -- and
+ * from it the 16-bit table entries -- BIT FOR BIT (the reference's own check is the round trip of
+ * src/test/multiscale_tester.py:373).  So every change that alters a bit of P on purpose (a different summation order in a decoder-side
+ * convolution, a different transcendental in the mixture head, another compiler contraction setting) bumps this number, and files of
+ * an older generation are NOT readable by this build.  tests/golden/hip_*.l3c + hip_bitstream.json are files and P hashes written by the
+ * generation they name; tests/test_gpu_bitstream.py fails when today's build no longer decodes them or no longer reproduces the hashes
+ * (i.e. when a kernel changed P bits WITHOUT the bump).  `l3c.py enc` prints it.
+ *   1  rounds 1-2 (F(2x2,3x3) convolutions)        2  round 3 (F(4x4,3x3), polyphase 5x5)        3  round 5 (fused multiply-adds in the 3->64 head)
+ */
+#define L3C_BITSTREAM_GENERATION 3
+int l3c_bitstream_generation(void);
 /* Thread-local description of the last failing call ("" if none). */
 const char *l3c_last_error(void);
 /* Name / CU count / gcnArchName of the current HIP device; fails when no GPU is visible (there is no CPU fallback). */
@@ -171,6 +184,44 @@ int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_strea
 
 int l3c_cdf_check_monotone(const uint16_t *cdf, int64_t n_rows, int Lp, int32_t *flag_out, l3c_stream_t stream);
 
+/*
+ * The whole RGB scale of a batch in ONE host call (round 6): the chunk-pipelined decode of R, G and B -- channel c's table at a pixel
+ * needs the channels < c decoded at that pixel (reference: criterion/logistic_mixture.py:262-272; the per-channel decoder loop it
+ * replaces: bitcoding/bitcoding.py:212-266 -> torchac.cpp:299-381).  Pipeline step t handles chunk t - lag * c of channel c: ONE
+ * grouped table launch (l3c_dmll_cdf_table_parts) on `main_stream`, then ONE grouped decoder launch (l3c_ac_decode_chunks) on
+ * `side_stream` (lag 2: the tables of step t + 1 are built while step t decodes; lag 1: everything on main_stream, side_stream unused).
+ * Returns with everything enqueued and main_stream ordered after the last symbols; no host synchronisation, no allocation: table
+ * slots, coder states, validity flags and window statistics live in the caller's workspace (l3c_decode_rgb_workspace_bytes).
+ *   P            fp32 pixel-major [B][HW][120] (K = 10: 4 * 3 * K)      targets  fp32 [257]
+ *   sym          int16 planar [B][3][HW], ZEROED by the caller; receives the symbols, read back for the lambda coupling
+ *   in / in_offsets / in_nbytes   the streams, CHANNEL-major: stream (c, b) at index c * B + b (4-byte aligned, zero padded: l3c_container_read)
+ *   chunks       n_chunks (pix0, npix) ranges tiling [0, HW) in order, boundaries on multiples of 64; HOST arrays
+ *   window_mode  0: full 257-entry rows; 1: 65-entry window rows wherever the stream's statistics two chunks earlier say that pays
+ *                (see l3c_ac_decode_part; the first two chunks of a channel are then decoded on full rows: make them short probes);
+ *                2: window rows from the first chunk on (tests)
+ */
+typedef struct {
+    const float *P;
+    const float *targets;
+    int16_t *sym;
+    int64_t B, HW;
+    int K;
+    const uint8_t *in;
+    const int64_t *in_offsets;
+    const uint32_t *in_nbytes;
+    int n_chunks;
+    const int64_t *chunk_pix0_host;
+    const int64_t *chunk_npix_host;
+    int lag;
+    int window_mode;
+    void *workspace;
+    int64_t workspace_bytes;
+} l3c_rgb_decode_desc;
+int64_t l3c_decode_rgb_workspace_bytes(int64_t B, int64_t max_chunk_npix, int n_chunks, int lag);
+/* byte offset, inside the workspace, of the window statistics int32 [3][n_chunks + 2][B] (slot j + 2 = what chunk j's decoders reported; tests) */
+int64_t l3c_decode_rgb_stats_offset(int64_t B, int64_t max_chunk_npix, int n_chunks, int lag);
+int l3c_decode_rgb(const l3c_rgb_decode_desc *desc_host, l3c_stream_t main_stream, l3c_stream_t side_stream);
+
 /* ---- logistic-mixture head (replaces torchac_kernel.cu + criterion/logistic_mixture.py on the coding path) --------- */
 
 /*
@@ -206,6 +257,21 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
 int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
                        int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, const int32_t *window_stats,
                        l3c_stream_t stream);
+
+/*
+ * Grouped form (round 6): the tables of 1..8 parts -- the channels of one pipeline step of the RGB decode, each over its own pixel
+ * range, or the C channels of a bottleneck scale -- in ONE launch.  Parts share P, sym, targets and the shape; every part's arguments as
+ * for l3c_dmll_cdf_table.  `parts_host` is a HOST array.
+ */
+typedef struct {
+    int c;
+    int64_t pix0, npix;
+    uint16_t *cdf;               /* [B][npix][Lp] */
+    int32_t *not_monotone;       /* may be NULL */
+    const int32_t *window_stats; /* may be NULL */
+} l3c_table_part;
+int l3c_dmll_cdf_table_parts(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
+                             int Lp, const l3c_table_part *parts_host, int n_parts, l3c_stream_t stream);
 
 /*
  * Fused encoder head: straight from the network output P and the symbols to the packed coding intervals of every
@@ -384,6 +450,20 @@ typedef struct {
 } l3c_container_scale;
 int l3c_container_write(const l3c_container_scale *scales, int n_scales, int64_t B, const uint16_t *padding,
                         const int64_t *file_offset, uint8_t *dst, l3c_stream_t stream);
+
+/*
+ * The inverse for the decoder (round 6): the entropy-coded streams of MANY files, which lie at arbitrary byte offsets inside the files
+ * (bitcoding.py:326-375: u32 nbytes + payload per channel), copied out of ONE device buffer holding the raw files into the form the
+ * range decoder reads -- every stream 4-byte aligned and followed by at least 4 zero bytes (bits past the end read 0, torchac.cpp:96-128).
+ * The host parses only the framing (a few length fields per file) and uploads the files as they are, in one copy.
+ *   files        the raw bytes of the files, back to back (device), 4-byte aligned and readable up to the next multiple of 4 of its size
+ *   src_offset   int64 [n_streams]: byte position of stream s's payload inside `files`
+ *   dst_offset   int64 [n_streams]: byte position of stream s inside `dst`, a multiple of 4; the caller leaves ((nbytes + 3) / 4) * 4 + 4
+ *                bytes per stream, all of which are written (payload, then zeros)
+ *   nbytes       uint32 [n_streams];   max_nbytes   the largest of them (the host has read every length field: it sizes the launch)
+ */
+int l3c_container_read(const uint8_t *files, const int64_t *src_offset, const int64_t *dst_offset, const uint32_t *nbytes,
+                       int64_t n_streams, uint32_t max_nbytes, uint8_t *dst, l3c_stream_t stream);
 
 /* symbols -> bottleneck values, to_bn (quantizer.py:44-47): float(S) * bin + x_min, two separately rounded fp32 ops. */
 int l3c_sym_to_bn(const int16_t *sym, int64_t n, float bin_width, float x_min, float *bn, l3c_stream_t stream);

@@ -50,12 +50,26 @@ class AcDecodePart(ctypes.Structure):
                 ('HW', c_i64), ('pix0', c_i64), ('C', c_int), ('K', c_int), ('c', c_int)]
 
 
+class TablePart(ctypes.Structure):
+    """l3c_table_part (include/l3c_hip.h)."""
+    _fields_ = [('c', c_int), ('pix0', c_i64), ('npix', c_i64), ('cdf', c_vp), ('not_monotone', c_vp), ('window_stats', c_vp)]
+
+
+class RgbDecodeDesc(ctypes.Structure):
+    """l3c_rgb_decode_desc (include/l3c_hip.h)."""
+    _fields_ = [('P', c_vp), ('targets', c_vp), ('sym', c_vp), ('B', c_i64), ('HW', c_i64), ('K', c_int),
+                ('in_', c_vp), ('in_offsets', c_vp), ('in_nbytes', c_vp), ('n_chunks', c_int),
+                ('chunk_pix0_host', ctypes.POINTER(c_i64)), ('chunk_npix_host', ctypes.POINTER(c_i64)),
+                ('lag', c_int), ('window_mode', c_int), ('workspace', c_vp), ('workspace_bytes', c_i64)]
+
+
 EPI_RELU, EPI_RESIDUAL, EPI_PIXEL_SHUFFLE = 1, 2, 4
-ABI_VERSION = 3      # include/l3c_hip.h: L3C_ABI_VERSION (3: window rows in l3c_dmll_cdf_table / l3c_ac_decode_part)
+ABI_VERSION = 4      # include/l3c_hip.h: L3C_ABI_VERSION (4: grouped tables, l3c_decode_rgb, l3c_container_read; no canvas batches)
 
 # name -> (restype, argtypes); must list every symbol include/l3c_hip.h declares (tests/test_abi.py checks)
 PROTOTYPES = {
     'l3c_abi_version': (c_int, []),
+    'l3c_bitstream_generation': (c_int, []),
     'l3c_last_error': (ctypes.c_char_p, []),
     'l3c_device_info': (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
     'l3c_stream_create_cu_range': (c_int, [c_int, c_int, ctypes.POINTER(c_vp)]),
@@ -68,6 +82,11 @@ PROTOTYPES = {
     'l3c_ac_encode_groups_workspace_bytes': (c_i64, [c_int, c_i64]),
     'l3c_ac_encode_groups': (c_int, [ctypes.POINTER(AcGroup), c_int, c_vp, c_vp]),
     'l3c_container_write': (c_int, [ctypes.POINTER(ContainerScale), c_int, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    'l3c_container_read': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, ctypes.c_uint32, c_vp, c_vp]),
+    'l3c_dmll_cdf_table_parts': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_int, ctypes.POINTER(TablePart), c_int, c_vp]),
+    'l3c_decode_rgb_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_int]),
+    'l3c_decode_rgb_stats_offset': (c_i64, [c_i64, c_i64, c_int, c_int]),
+    'l3c_decode_rgb': (c_int, [ctypes.POINTER(RgbDecodeDesc), c_vp, c_vp]),
     'l3c_ac_decode_state_bytes': (c_i64, []),
     'l3c_ac_decode_chunks': (c_int, [ctypes.POINTER(AcDecodePart), c_int, c_vp]),
     'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),

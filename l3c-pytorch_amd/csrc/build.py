@@ -10,7 +10,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_pw.hip', 'conv_wino4.hip']
+SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_pw.hip', 'conv_wino4.hip', 'decode_pipeline.hip']
 # test-only second library (include/l3c_xcheck.h): the round-1/2 Winograd F(2x2,3x3) kernel, an independent implementation the tests
 # compare the product's kernels with.  The product library does not contain it and the package never loads it outside the tests.
 XCHECK_SOURCES = ['l3c_api.hip', 'conv_wino.hip', 'xcheck_dmll.hip']

@@ -83,9 +83,46 @@ __global__ __launch_bounds__(256) void container_write_kernel(const ContainerArg
     if (threadIdx.x < n - tail0) dst[tail0 + threadIdx.x] = src[tail0 + threadIdx.x];
 }
 
+// one block per (stream, 16 KB slice of its padded length): output dword i = source bytes 4 i .. 4 i + 3 (zero beyond the payload)
+__global__ __launch_bounds__(256) void container_read_kernel(const uint8_t *__restrict__ files, const int64_t *__restrict__ src_offset,
+                                                             const int64_t *__restrict__ dst_offset, const uint32_t *__restrict__ nbytes,
+                                                             uint8_t *__restrict__ dst) {
+    const int64_t s = blockIdx.y;
+    const uint32_t n = nbytes[s];
+    const uint32_t words = (n + 3) / 4 + 1;                  // the padded stream: payload, zeros up to a dword, one zero dword
+    const uint8_t *src = files + src_offset[s];
+    uint32_t *out = reinterpret_cast<uint32_t *>(dst + dst_offset[s]);
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 3);
+    const uint32_t *src_w = reinterpret_cast<const uint32_t *>(src - mis);   // aligned words around the payload (inside the file buffer)
+    const uint32_t last = (mis + n + 3) / 4;                 // aligned source words holding payload bytes: [0, last)
+    for (uint32_t i = blockIdx.x * 4096u + threadIdx.x; i < words && i < (blockIdx.x + 1) * 4096u; i += 256u) {
+        uint32_t v = 0;
+        if (4 * i < n) {
+            const uint32_t lo = src_w[i];
+            const uint32_t hi = (i + 1 < last) ? src_w[i + 1] : 0u;
+            v = mis ? __builtin_amdgcn_alignbyte(hi, lo, mis) : lo;
+            const uint32_t left = n - 4 * i;                 // payload bytes in this dword (1..4 of them when left < 4)
+            if (left < 4) v &= (1u << (8 * left)) - 1u;
+        }
+        out[i] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int l3c_container_read(const uint8_t *files, const int64_t *src_offset, const int64_t *dst_offset, const uint32_t *nbytes,
+                       int64_t n_streams, uint32_t max_nbytes, uint8_t *dst, l3c_stream_t stream) {
+    L3C_REQUIRE(files && src_offset && dst_offset && nbytes && dst, "null pointer");
+    L3C_REQUIRE(n_streams > 0 && n_streams < 65536, "1..65535 streams per call");
+    L3C_REQUIRE((reinterpret_cast<uintptr_t>(files) & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0, "buffers must be 4-byte aligned");
+    // grid.x covers the longest stream (the host has read every length field); a block whose slice lies beyond its own stream does nothing
+    const unsigned slices = (unsigned)(((uint64_t)max_nbytes + 3) / 4 + 1 + 4095) / 4096;
+    hipLaunchKernelGGL(container_read_kernel, dim3(slices, (unsigned)n_streams), dim3(256), 0, l3c::as_stream(stream), files, src_offset,
+                       dst_offset, nbytes, dst);
+    return l3c::check_launch("container_read_kernel");
+}
 
 int l3c_container_write(const l3c_container_scale *scales, int n_scales, int64_t B, const uint16_t *padding,
                         const int64_t *file_offset, uint8_t *dst, l3c_stream_t stream) {

@@ -190,19 +190,40 @@ __global__ __launch_bounds__(256) void cdf_table_kernel(const float *__restrict_
 // whose entry Lp - 1 (never read by any coder: the top symbol's upper bound is 2^16) then carries the window offset, so that a decoder
 // working on full rows can still count what a window would have missed.  Either way image b's rows start at its full-size slot
 // cdf + b * range_len * Lp.
+// GROUPED (round 6): blockIdx.z picks one of up to kMaxTableParts parts -- the channels of one pipeline step of the RGB decode (R chunk
+// j, G chunk j - D, B chunk j - 2 D) or the C channels of a bottleneck scale -- so that a step's tables are ONE launch (the decode was
+// within 30 % of being bound by the host's launch rate).  Parts share P, sym, targets and the shape; ranges may differ in length (grid.x
+// covers the longest; the surplus blocks of a shorter part leave at once).
+constexpr int kMaxTableParts = 8;
+struct TablePart {
+    int c;
+    int64_t range0, range_len;
+    uint16_t *cdf;
+    int32_t *not_monotone;
+    const int32_t *win_stats;
+};
+struct TableParts {
+    TablePart part[kMaxTableParts];
+};
+
 __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
                                                                const float *__restrict__ targets, int64_t HW, int C, int K,
-                                                               int rgb, int c, int64_t range0, int64_t range_len, int Lp,
-                                                               uint16_t *__restrict__ cdf, int32_t *__restrict__ not_monotone,
-                                                               const int32_t *__restrict__ win_stats, TileDiv dv) {
+                                                               int rgb, int Lp, const TableParts parts, TileDiv dv) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [kTablePix][Kp + 1]
     __shared__ float s_pi[kTablePix][kMaxK], s_mu[kTablePix][kMaxK], s_inv[kTablePix][kMaxK];
     __shared__ float s_e[kTablePix][kMaxK], s_max[kTablePix];
     __shared__ float s_t[260];
+    const TablePart &part = parts.part[blockIdx.z];
+    const int c = part.c;
+    const int64_t range0 = part.range0, range_len = part.range_len;
+    uint16_t *__restrict__ cdf = part.cdf;
+    int32_t *__restrict__ not_monotone = part.not_monotone;
+    const int32_t *__restrict__ win_stats = part.win_stats;
     const int Kp = (rgb ? 4 : 3) * C * K;
     const int ld = Kp + 1;
     const int64_t b = blockIdx.y;
     const int64_t off = (int64_t)blockIdx.x * kTablePix;          // offset inside the range
+    if (off >= range_len) return;                                 // (uniform: a shorter part of a grouped launch)
     const int64_t pix0 = range0 + off;
     const int npix = (int)((range_len - off) < kTablePix ? (range_len - off) : kTablePix);
     const int tid = threadIdx.x;
@@ -559,25 +580,46 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
     return rc;
 }
 
-int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
-                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, const int32_t *window_stats,
-                       l3c_stream_t stream) {
-    L3C_REQUIRE(P && targets && cdf, "null pointer");
-    L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0 && c >= 0 && c < C, "bad shape");
-    L3C_REQUIRE(pix0 >= 0 && npix > 0 && pix0 + npix <= HW, "pixel range outside the image");
+static int cdf_table_parts_launch(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
+                                  int Lp, const l3c_table_part *parts, int n_parts, l3c_stream_t stream) {
+    L3C_REQUIRE(P && targets && parts, "null pointer");
+    L3C_REQUIRE(n_parts > 0 && n_parts <= kMaxTableParts, "1..8 parts per call");
+    L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0, "bad shape");
     L3C_REQUIRE(K > 0 && K <= kMaxK, "K out of range (1..16)");
     L3C_REQUIRE(Lp >= 2 && Lp <= 260, "Lp out of range (2..260)");
     L3C_REQUIRE(!rgb || C == 3, "lambda coupling is only defined for C == 3");
-    L3C_REQUIRE(!(rgb && c > 0) || sym, "the RGB scale needs the symbols of the channels decoded so far");
-    L3C_REQUIRE(!window_stats || Lp == 257, "window rows are defined for the 256-symbol alphabet (Lp == 257)");
     const int Kp = (rgb ? 4 : 3) * C * K;
     const size_t lds = (size_t)kTablePix * (Kp + 1) * sizeof(float);
     L3C_REQUIRE(lds <= 48 * 1024, "Kp too large for the LDS tile");
-    const dim3 grid((unsigned)((npix + kTablePix - 1) / kTablePix), (unsigned)B);
-    hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, c,
-                       pix0, npix, Lp, cdf, not_monotone, window_stats, tile_div(Kp, kTablePix));
-    int rc = l3c::check_launch("cdf_table_from_P_kernel");
-    return rc;   // (the kernel has checked the rows while it held them: not_monotone)
+    TableParts tp{};
+    int64_t longest = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        const l3c_table_part &q = parts[i];
+        L3C_REQUIRE(q.cdf, "null table pointer in part");
+        L3C_REQUIRE(q.c >= 0 && q.c < C, "channel out of range");
+        L3C_REQUIRE(q.pix0 >= 0 && q.npix > 0 && q.pix0 + q.npix <= HW, "pixel range outside the image");
+        L3C_REQUIRE(!(rgb && q.c > 0) || sym, "the RGB scale needs the symbols of the channels decoded so far");
+        L3C_REQUIRE(!q.window_stats || Lp == 257, "window rows are defined for the 256-symbol alphabet (Lp == 257)");
+        tp.part[i] = TablePart{q.c, q.pix0, q.npix, q.cdf, q.not_monotone, q.window_stats};
+        longest = q.npix > longest ? q.npix : longest;
+    }
+    const dim3 grid((unsigned)((longest + kTablePix - 1) / kTablePix), (unsigned)B, (unsigned)n_parts);
+    hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, Lp, tp,
+                       tile_div(Kp, kTablePix));
+    return l3c::check_launch("cdf_table_from_P_kernel");   // (the kernel has checked the rows while it held them: not_monotone)
+}
+
+int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
+                       int c, int64_t pix0, int64_t npix, int Lp, uint16_t *cdf, int32_t *not_monotone, const int32_t *window_stats,
+                       l3c_stream_t stream) {
+    L3C_REQUIRE(cdf, "null pointer");
+    const l3c_table_part part{c, pix0, npix, cdf, not_monotone, window_stats};
+    return cdf_table_parts_launch(P, sym, targets, B, HW, C, K, rgb, Lp, &part, 1, stream);
+}
+
+int l3c_dmll_cdf_table_parts(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
+                             int Lp, const l3c_table_part *parts_host, int n_parts, l3c_stream_t stream) {
+    return cdf_table_parts_launch(P, sym, targets, B, HW, C, K, rgb, Lp, parts_host, n_parts, stream);
 }
 
 int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C,

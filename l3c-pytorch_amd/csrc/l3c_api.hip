@@ -13,6 +13,7 @@ char *error_buffer() {
 extern "C" {
 
 int l3c_abi_version(void) { return L3C_ABI_VERSION; }
+int l3c_bitstream_generation(void) { return L3C_BITSTREAM_GENERATION; }
 
 const char *l3c_last_error(void) { return l3c::error_buffer(); }
 

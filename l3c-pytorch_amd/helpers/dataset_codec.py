@@ -204,3 +204,72 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
     if marks is not None:
         marks['host seconds'] = dict(spent)
     return files, n_shapes, len(chunks)
+
+
+def file_padded_shape(data):
+    """(H, W) of the PADDED image a `.l3c` byte string holds, from its first (coarsest) scale record alone: u16 x4 padding, then
+    u8 C, u16 H, u16 W of the coarsest scale (reference bitcoding.py:326-375) -- the image is 2**(records - 1) times that.  Cheap: the
+    record count comes from walking the length fields, no payload is touched."""
+    import struct
+    from ..bitcoding.bitcoding import count_scale_records
+    n = count_scale_records(data)
+    _, H, W = struct.unpack_from('<BHH', data, 8)
+    return (H << (n - 1), W << (n - 1))
+
+
+def plan_decode_set(files, order, max_batch):
+    """Host-side plan of a set decode: files of equal padded shape share a batch of at most max_batch (the mirror of plan_set, from
+    the files' own headers).  -> (chunks: list of index lists, padded shape per chunk)."""
+    groups = collections.defaultdict(list)
+    for i in order:
+        groups[file_padded_shape(files[i])].append(i)
+    chunks, padded = [], []
+    for shape, idxs in groups.items():
+        for k in range(0, len(idxs), max_batch):
+            chunks.append(idxs[k:k + max_batch])
+            padded.append(shape)
+    return chunks, padded
+
+
+def decode_set(bc, files, order, max_batch=16, marks=None):
+    """files: {index: `.l3c` bytes} (as `encode_set` returns them); order: the indices to decode.  -> {index: uint8 (3,H,W) HOST tensor},
+    the padding undone.  The mirror of `encode_set` for the reference's folder evaluation, which decodes EVERY file it wrote and
+    compares it with the input (multiscale_tester.py:353-381, assert_equal at :373): files of equal padded shape share a batch,
+    largest batches first, every batch through `Bitcoding.decode_many`; the decoded pixels leave the device as uint8 through a
+    page-locked buffer per batch while the next batch decodes."""
+    import time
+    from . import pad as _pad
+
+    def mark(name):
+        if marks is not None:
+            marks[name] = time.perf_counter()
+
+    chunks, padded = plan_decode_set(files, order, max_batch)
+    by_size = sorted(range(len(chunks)), key=lambda k: -len(chunks[k]) * padded[k][0] * padded[k][1])
+    mark('plan (host)')
+    out, pending = {}, []
+
+    def collect(block):
+        while pending and (block or pending[0][2].query()):
+            ci, host, ev, paddings = pending.pop(0)
+            ev.synchronize()
+            for k, i in enumerate(chunks[ci]):
+                img = host[k]
+                if any(paddings[k]):
+                    img = _pad.undo_pad(img.unsqueeze(0), *paddings[k])[0]
+                out[i] = img.clone()
+
+    def on_batch(n, pixels, paddings):
+        ci = by_size[n]
+        u8 = pixels.to(torch.uint8)                       # 0..255 by construction (symbols of a 256-symbol alphabet)
+        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        host.copy_(u8, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        pending.append((ci, host, ev, paddings))
+        collect(False)
+
+    bc.decode_many([[files[i] for i in chunks[ci]] for ci in by_size], on_batch=on_batch)
+    collect(True)
+    mark('parse + H2D + decode + D2H (pipelined)')
+    return out

@@ -380,6 +380,59 @@ def dmll_cdf_table(P_nhwc, sym, targets, C, K, rgb, c, pix0, npix, flag=None, wi
     return cdf
 
 
+def dmll_cdf_table_parts(P_nhwc, sym, targets, C, K, rgb, parts):
+    """Grouped form of `dmll_cdf_table` (l3c_dmll_cdf_table_parts): parts = [(c, pix0, npix, flag or None, window_stats or None)], up to 8,
+    ONE launch.  -> list of tables (int16 (B, npix, Lp)) in the order of `parts`."""
+    B, H, W, _ = P_nhwc.shape
+    Lp = targets.shape[0]
+    arr = (_lib.TablePart * len(parts))()
+    tables = []
+    for i, (c, pix0, npix, flag, wstats) in enumerate(parts):
+        t = torch.empty(B, npix, Lp, dtype=torch.int16, device=P_nhwc.device)
+        tables.append(t)
+        arr[i] = _lib.TablePart(c, pix0, npix, ptr(t), ptr(flag, torch.int32) if flag is not None else None,
+                                ptr(wstats, torch.int32) if wstats is not None else None)
+    call('l3c_dmll_cdf_table_parts', ptr(P_nhwc, torch.float32), ptr(sym, torch.int16) if sym is not None else None,
+         ptr(targets, torch.float32), B, H * W, C, K, int(rgb), Lp, arr, len(parts), stream())
+    return tables
+
+
+def decode_rgb(P_nhwc, targets, sym, buf, offs, lens, bounds, K, lag, window_mode, side_stream=None):
+    """The whole RGB scale in one host call (l3c_decode_rgb): P (B,H,W,120), sym int16 (B,3,H,W) ZEROED (receives the symbols), the streams
+    CHANNEL-major in (buf, offs int64 (3B,), lens int32 (3B,)), bounds = [(pix0, npix)] tiling H*W.  lag 2 decodes on `side_stream` (a
+    torch stream) while the current stream builds the next step's tables.  -> (workspace tensor, window statistics view (3, chunks + 2, B)
+    or None); the current stream is ordered after the last symbols."""
+    import ctypes
+    lib = _lib.load()
+    B, H, W, _ = P_nhwc.shape
+    n = len(bounds)
+    max_npix = max(b[1] for b in bounds)
+    nbytes = lib.l3c_decode_rgb_workspace_bytes(B, max_npix, n, lag)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=P_nhwc.device)
+    p0 = (_lib.c_i64 * n)(*[b[0] for b in bounds])
+    np_ = (_lib.c_i64 * n)(*[b[1] for b in bounds])
+    desc = _lib.RgbDecodeDesc(ptr(P_nhwc, torch.float32), ptr(targets, torch.float32), ptr(sym, torch.int16), B, H * W, K,
+                              ptr(buf, torch.uint8), ptr(offs, torch.int64), ptr(lens, torch.int32), n,
+                              ctypes.cast(p0, ctypes.POINTER(_lib.c_i64)), ctypes.cast(np_, ctypes.POINTER(_lib.c_i64)),
+                              lag, window_mode, ptr(ws), nbytes)
+    main = torch.cuda.current_stream()
+    if lag == 2:
+        for t in (P_nhwc, targets, sym, buf, offs, lens, ws):
+            t.record_stream(side_stream)
+    call('l3c_decode_rgb', ctypes.byref(desc), main.cuda_stream, side_stream.cuda_stream if lag == 2 else None)
+    stats = None
+    if window_mode:
+        o = lib.l3c_decode_rgb_stats_offset(B, max_npix, n, lag)
+        stats = ws[o:o + 3 * (n + 2) * B * 4].view(torch.int32).view(3, n + 2, B)
+    return ws, stats
+
+
+def container_read(files_dev, src_off, dst_off, nbytes, max_nbytes, dst):
+    """l3c_container_read: the streams of many raw `.l3c` files (one device buffer) -> 4-byte aligned, zero padded streams in `dst`."""
+    call('l3c_container_read', ptr(files_dev, torch.uint8), ptr(src_off, torch.int64), ptr(dst_off, torch.int64), ptr(nbytes, torch.int32),
+         nbytes.numel(), int(max_nbytes), ptr(dst, torch.uint8), stream())
+
+
 def dmll_encode_intervals(P_nhwc, sym, targets, C, K, rgb):
     """P (B,H,W,Kp), sym int16 (B,C,H,W) -> packed interval words for the B*C streams of this scale."""
     B, H, W, _ = P_nhwc.shape

@@ -416,7 +416,9 @@ class MultiscaleTester(object):
             raise EncodeError('{} exists. Consider --overwrite'.format(pout))
         img = self._read_img(img_p)
         bpsp = self.bc.encode(img, pout=pout)
-        print('---\nSaved:', pout)
+        from .. import _lib
+        # the container has no version field (reference bitcoding.py:326-375): say which decoder generation reads this file
+        print('---\nSaved: {}  (bitstream generation {}, include/l3c_hip.h)'.format(pout, _lib.load().l3c_bitstream_generation()))
         return bpsp
 
     def decode(self, pin, png_out_p):

@@ -25,7 +25,9 @@ def test_library_is_built_and_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert sorted(_lib.PROTOTYPES) == names
-    assert lib.l3c_abi_version() == _lib.ABI_VERSION == 3
+    assert lib.l3c_abi_version() == _lib.ABI_VERSION == 4
+    hdr = open(os.path.join(ROOT, 'include', 'l3c_hip.h')).read()
+    assert lib.l3c_bitstream_generation() == int(re.search(r'#define L3C_BITSTREAM_GENERATION (\d+)', hdr).group(1)) >= 3
     # the product library holds ONE generation of convolution kernels: the F(2x2,3x3) cross-check kernel lives in the test-only
     # library (include/l3c_xcheck.h), which exports exactly what that header declares
     assert not any(n.startswith('l3c_conv_wino_') or n == 'l3c_conv_wino' for n in names)

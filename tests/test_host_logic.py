@@ -385,3 +385,32 @@ def test_pmc_table_is_accepted_per_kernel_source(tmp_path, monkeypatch):
     monkeypatch.undo()
     t, state = bench.load_pmc_table()
     assert state == 'current', 'profiles/{} was taken on other sources of the roofline kernels: regenerate it (tools/make_evidence.sh)'.format(bench.PMC_TABLE)
+
+
+def test_committed_hip_bitstream_fixtures_are_intact():
+    """tests/golden/hip_*.l3c were written by the HIP path of the generation hip_bitstream.json names (tests/golden/make_hip_bitstream.py on an
+    MI355X); the GPU suite decodes them with today's build (tests/test_gpu_bitstream.py).  Here, without a GPU: the files are the ones the
+    record describes, their framing parses, the inputs they must decode to are the committed fixture images, and the record is of the
+    generation the header declares."""
+    import hashlib
+    import json
+    import re
+    import numpy as np
+    from l3c_pytorch_amd.bitcoding.bitcoding import count_scale_records, parse_containers
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    golden = os.path.join(root, 'tests', 'golden')
+    rec = json.load(open(os.path.join(golden, 'hip_bitstream.json')))
+    hdr = open(os.path.join(root, 'include', 'l3c_hip.h')).read()
+    assert rec['bitstream_generation'] == int(re.search(r'#define L3C_BITSTREAM_GENERATION (\d+)', hdr).group(1))
+    for name, records, img_file in (('hip_l3c_cal_64x96.l3c', 4, 'net_cal_64x96.npz'), ('hip_rgb_shared_32x48_r3.l3c', 5, 'net_rgb_32x48.npz')):
+        data = open(os.path.join(golden, name), 'rb').read()
+        meta = rec['files'][name]
+        assert len(data) == meta['bytes'] and hashlib.sha256(data).hexdigest() == meta['sha256']
+        assert count_scale_records(data) == records
+        p = parse_containers([data])
+        assert p.padding == [(0, 0, 0, 0)] and len(p.scales) == records
+        H, W = meta['shape'][-2:]
+        assert p.scales[-1][1:] == (H, W) and p.scales[0][1:] == (H >> (records - 1), W >> (records - 1))
+        img = np.load(os.path.join(golden, img_file))['img']
+        assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == meta['pixels_sha256']
+    assert all(len(rec['forward_64x96'][k]['P']) == 3 and len(rec['forward_64x96'][k]['S']) == 4 for k in ('default', 'calibrated'))
