@@ -63,13 +63,14 @@ def parse_args(argv=None):
     ap.add_argument('--gpus', type=int, default=None, help='ranks = GPUs (default: the launcher\'s WORLD_SIZE, else 1)')
     ap.add_argument('--steps', type=int, default=None)
     ap.add_argument('--warmup', type=int, default=None)
-    ap.add_argument('--config', choices=('headline', 'dataset', 'large'), default='headline')
+    ap.add_argument('--config', choices=('headline', 'dataset', 'large', 'files'), default='headline')
     ap.add_argument('--batch', type=int, default=128, help='headline: images per GPU per step')
     ap.add_argument('--checkpoint', choices=('calibrated', 'default'), default='calibrated',
                     help='synthetic checkpoint: calibrated = fitted probability heads (live model, ~6 bpsp); default = seeded default '
                          'init (R and G streams at the 16-bit probability floor: the coder\'s worst case, 16.2 bpsp)')
     ap.add_argument('--images', type=int, default=500, help='dataset: images in the set (all ranks together)')
     ap.add_argument('--max-batch', type=int, default=16, help='dataset: images of one padded shape per forward pass')
+    ap.add_argument('--write-window', type=int, default=None, help='files: images the tester codes / decodes as one set (default 8 x max-batch)')
     ap.add_argument('--coder-cus', type=int, default=0, help='compute units reserved for the range coder (0 = share all CUs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-parity', action='store_true')
@@ -83,7 +84,7 @@ def parse_args(argv=None):
     a = ap.parse_args(argv)
     if a.gpus is None:      # under torch.distributed.run without --gpus: the launcher's world size is the truth
         a.gpus = int(os.environ.get('WORLD_SIZE', '1')) if 'RANK' in os.environ else 1
-    defaults = {'headline': (6, 2), 'dataset': (3, 1), 'large': (4, 1)}[a.config]     # (dataset: three timed passes over the set, each reported)
+    defaults = {'headline': (6, 2), 'dataset': (3, 1), 'large': (4, 1), 'files': (2, 1)}[a.config]     # (dataset: three timed passes over the set, each reported)
     a.steps = defaults[0] if a.steps is None else a.steps
     a.warmup = defaults[1] if a.warmup is None else a.warmup
     return a
@@ -630,7 +631,7 @@ def extra_legs(args):
                      'floor -- 2.6x the calibrated checkpoint\'s bitstream volume, ~6x a trained model\'s')
     ds = _sub_bench(['--config', 'dataset', '--images', '200', '--steps', '3', '--warmup', '1', '--checkpoint', args.checkpoint])
     lg = _sub_bench(['--config', 'large', '--steps', '4', '--warmup', '1', '--checkpoint', args.checkpoint])
-    keys = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'bpsp', 'megapixels', 'round_trip_of_2_images', 'per_step', 'config')
+    keys = ('metric', 'value', 'unit', 'ms_per_step', 'steps', 'warmup', 'bpsp', 'megapixels', 'decode', 'per_step', 'config')
     return {'worst_case_coder': worst,
             'configs': {'dataset': dict(pick(ds, keys), reduced='200 of the 500 images of BASELINE.json config 4 (python bench.py --config dataset runs all 500; the fill and drain of the host pipeline weigh more on the shorter set)'),
                         'large': dict(pick(lg, keys), reduced='4 steps of BASELINE.json config 5 (python bench.py --config large)')}}
@@ -654,8 +655,7 @@ def run_dataset(args, ranks):
 
     def step():
         t0 = time.perf_counter()
-        r = dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'],
-                                     canvas=os.environ.get('L3C_CANVAS', '0') != '0')
+        r = dataset_codec.encode_set(bc, imgs, mine, max_batch=args.max_batch, n_pinned=ranks.budget['pinned_buffers'])
         step_seconds.append(time.perf_counter() - t0)
         return r
 
@@ -665,11 +665,19 @@ def run_dataset(args, ranks):
     bits = sum(len(files[i]) for i in mine) * 8
     tot_px, tot_bits = ranks.sum_over_ranks([pixels, bits])
     value = tot_px * args.steps / 1e6 / elapsed
-    # round trip of two of the rank's images (outside the timed region)
-    for i in mine[:2]:
-        dec, padding = bc.decode_batch([files[i]])
-        out = pad.undo_pad(dec, *padding[0]) if any(padding[0]) else dec
-        assert torch.equal(out.cpu()[0], imgs[i].long()), 'round trip failed for image {}'.format(i)
+    # SET DECODE (round 6; outside the encode's timed region): EVERY file of the rank decoded back -- `.l3c` bytes on the host -> uint8 pixels
+    # on the host -- and compared with its input, like the reference's folder evaluation does (multiscale_tester.py:353-381, assert_equal :373);
+    # files of equal padded shape share a batch, the batches stream through Bitcoding.decode_many
+    dec_seconds, lanes = [], int(os.environ.get('L3C_DECODE_LANES', '0')) or None
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        back = dataset_codec.decode_set(bc, files, mine, max_batch=args.max_batch, lanes=lanes)
+        torch.cuda.synchronize()
+        dec_seconds.append(time.perf_counter() - t0)
+    wrong = [i for i in mine if not torch.equal(back[i], imgs[i])]
+    assert not wrong, 'set decode is not lossless for images {}'.format(wrong[:8])
+    dec_best = min(dec_seconds[1:])
     result = None
     if ranks.rank == 0:
         name, ncu, arch = _lib.device_info()
@@ -682,13 +690,115 @@ def run_dataset(args, ranks):
                     'forward_launches_on_rank0': n_launches, 'max_batch': args.max_batch,
                     'sharding': 'largest-first greedy on pixel counts (helpers/sharding.shard_balanced), replicas only',
                     'pixels_on_rank0_over_mean': round(pixels * ranks.world / tot_px, 4)},
-            bpsp=round(tot_bits / (3 * tot_px), 4), megapixels=round(tot_px / 1e6, 1), round_trip_of_2_images='lossless',
+            bpsp=round(tot_bits / (3 * tot_px), 4), megapixels=round(tot_px / 1e6, 1),
+            decode={'value': round(pixels / 1e6 / dec_best, 2), 'unit': 'MPix/s', 'images_decoded_on_rank0': len(mine), 'lossless': 'every image compared with its input',
+                    'seconds_rank0': [round(t, 4) for t in dec_seconds], 'timing': 'best of the two passes after the first one of the process',
+                    'lanes': lanes or bc.N_DECODE_LANES,
+                    'note': 'host .l3c bytes -> host uint8 pixels of EVERY file the encode leg wrote (dataset_codec.decode_set): framing parsed on the host, '
+                            'files uploaded as they are, batches of equal padded shape streamed through Bitcoding.decode_many'},
             per_step={'seconds_rank0': [round(t, 4) for t in step_seconds],
                       'mpix_per_s_rank0_best': round(pixels / 1e6 / min(step_seconds), 2),
                       'mpix_per_s_rank0_median': round(pixels / 1e6 / sorted(step_seconds)[len(step_seconds) // 2], 2),
                       'mpix_per_s_rank0_worst': round(pixels / 1e6 / max(step_seconds), 2)},
             device='{} ({}, {} CUs)'.format(name, arch, ncu), peak_hbm_gb=round(torch.cuda.max_memory_allocated() / 1e9, 1))
     return result
+
+
+# ---- files: the reference's own benchmark loop -- image FILES on disk -> `.l3c` files on disk -> decoded and compared -----------------------
+
+
+def run_files(args, ranks):
+    """`python test.py LOG_DIR 0306_0001 IMAGES --write_to_files D --time_report P` (reference test.py:44-104 ->
+    test/multiscale_tester.py:272-381, timed by its StackTimeLogger, test/cuda_timer.py:107-151; image read:
+    dataloaders/images_loader.py:91-129), measured file to file: N synthetic images are written as PNG files to a temporary
+    directory (outside the timed region), then the tester reads and decodes them on worker threads, codes them in windows (encode_set),
+    writes the `.l3c` files, reads them back, decodes them (decode_set) and compares every image with its input.  Two figures: encode
+    (PNG files -> `.l3c` files on disk) and the full round trip; the time report names the stages."""
+    import concurrent.futures
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import types
+    from PIL import Image
+    import l3c_pytorch_amd  # noqa: F401
+    from l3c_pytorch_amd import _lib
+    from l3c_pytorch_amd.helpers import config_parser, dataset_codec, sharding, synthetic
+    from l3c_pytorch_amd.helpers.testset import Testset
+    from l3c_pytorch_amd.test.multiscale_tester import MultiscaleTester
+    cfg = config_parser.parse_builtin('ms', 'cr')
+    sd = synthetic.make_state_dict(cfg, 0, calibrated=args.checkpoint == 'calibrated')
+    sizes = dataset_codec.draw_sizes(args.images)
+    mine = sharding.shard_balanced([h * w for h, w in sizes], ranks.rank, ranks.world)
+    root = tempfile.mkdtemp(prefix='l3c_files_bench_')
+    try:
+        ckpts = os.path.join(root, 'logs', '0306_0001 cr oi', 'ckpts')
+        os.makedirs(ckpts)
+        torch.save({'net': sd}, os.path.join(ckpts, 'ckpt_0000000001.pt'))
+        img_dir, out_dir = os.path.join(root, 'images'), os.path.join(root, 'written')
+        os.makedirs(img_dir)
+
+        def make_png(i):
+            img = synthetic.make_image(sizes[i][0], sizes[i][1], i, 'natural')
+            path = os.path.join(img_dir, 'img_{:05d}.png'.format(i))
+            Image.fromarray(img.permute(1, 2, 0).numpy()).save(path, compress_level=1)
+            return os.path.getsize(path)
+
+        with single_thread():
+            with concurrent.futures.ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as pool:
+                png_bytes = sum(pool.map(make_png, mine))
+        io_threads = max(ranks.budget['io_threads'], min(16, (os.cpu_count() or 1) // max(1, ranks.world) // 2))
+        report = os.path.join(root, 'times.txt')
+
+        def make_tester(round_trip):
+            flags = types.SimpleNamespace(log_dir=os.path.join(root, 'logs'), write_to_files=out_dir, time_report=report, batch=args.max_batch,
+                                          io_threads=io_threads, write_window=args.write_window, round_trip=round_trip, recursive='0')
+            return MultiscaleTester('0306_0001', flags, -1)
+
+        testset = Testset(img_dir)
+        pixels = sum(sizes[i][0] * sizes[i][1] for i in mine)
+        results = {}
+        for name, round_trip in (('encode', False), ('round_trip', True)):
+            tester = make_tester(round_trip)
+            secs = []
+
+            def step():
+                shutil.rmtree(out_dir, ignore_errors=True)
+                tester.times.times.clear()
+                t0 = time.perf_counter()
+                with contextlib.redirect_stdout(io.StringIO()), torch.no_grad():
+                    res = tester._test_write(testset)
+                secs.append(time.perf_counter() - t0)
+                return res
+
+            elapsed, res = timed(ranks, step, args.steps, args.warmup)
+            secs = secs[-args.steps:]
+            stages = {k: round(float(sum(v)), 4) for k, v in tester.times.times.items()}     # the last pass, its first window left out (the warm-up)
+            slowest = max(stages, key=stages.get) if stages else None
+            l3c_bytes = sum(os.path.getsize(os.path.join(out_dir, f)) for f in os.listdir(out_dir))
+            tot_px, = ranks.sum_over_ranks([pixels])
+            results[name] = {'value': round(tot_px * args.steps / 1e6 / elapsed, 2), 'unit': 'MPix/s', 'seconds_rank0': [round(t, 4) for t in secs],
+                             'bpsp': round(res.mean(), 4), 'l3c_bytes_rank0': l3c_bytes,
+                             'stage_seconds_last_pass_without_its_first_window': stages, 'slowest_stage': slowest}
+            elapsed_rt = elapsed
+        tot_px, = ranks.sum_over_ranks([pixels])
+        result = None
+        if ranks.rank == 0:
+            name, ncu, arch = _lib.device_info()
+            result = contract(
+                args, ranks, results['encode']['value'], elapsed_rt,
+                metric='MPix/s FILE TO FILE: image files (PNG) on disk -> .l3c files on disk (test.py --write_to_files), heterogeneous image set',
+                config={'workload': 'L3C 0306_0001, {} synthetic natural-like images as PNG files ({} MB on rank 0), sizes drawn like the reference\'s '
+                                    'Open Images preprocessing; the reference\'s own benchmark loop (test.py --write_to_files --time_report)'.format(
+                                        args.images, round(png_bytes / 1e6, 1)),
+                        'images': args.images, 'images_on_rank0': len(mine), 'max_batch': args.max_batch, 'write_window': args.write_window or 8 * args.max_batch,
+                        'io_threads': io_threads, 'temporary_directory': os.path.dirname(root)},
+                megapixels=round(tot_px / 1e6, 1), encode=results['encode'], round_trip=results['round_trip'],
+                device='{} ({}, {} CUs)'.format(name, arch, ncu))
+            result['ms_per_step'] = round(results['encode']['seconds_rank0'][-1] * 1e3, 3)
+        return result
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 # ---- large: RGB Shared baseline on 3000x2000 (auto-cropped) and 2000x1500 images ----------------------------------------------------
@@ -846,13 +956,13 @@ def main(argv=None):
         if rc != 0:
             raise SystemExit(rc)
         return None
-    if args.config == 'dataset':
+    if args.config in ('dataset', 'files'):
         from l3c_pytorch_amd.helpers import runtime as _runtime
         _runtime.configure_hip_queues()                   # several small forward passes side by side, see Bitcoding.encode_many (before HIP starts)
     ranks = Ranks(stub=args.stub_step)
     if args.gpus != ranks.world:
         raise SystemExit('bench.py: --gpus {} but the launcher started {} rank(s) (WORLD_SIZE)'.format(args.gpus, ranks.world))
-    run = run_stub if args.stub_step else {'headline': run_headline, 'dataset': run_dataset, 'large': run_large}[args.config]
+    run = run_stub if args.stub_step else {'headline': run_headline, 'dataset': run_dataset, 'large': run_large, 'files': run_files}[args.config]
     result = run(args, ranks)
     if ranks.rank == 0:
         print(json.dumps(result))

@@ -60,6 +60,10 @@ int l3c_device_info(char *name_host, int name_cap, int *num_cu_host, char *arch_
  * batch run on the complementary range: co-resident MFMA waves slow the coder's serial chain down 2.3x otherwise.
  */
 int l3c_stream_create_cu_range(int first_cu, int n_cu, l3c_stream_t *stream_out_host);
+/* The general form: bit i of the mask (32 CUs per word, `mask_host` is a HOST array of n_words words) = compute unit i may run this stream's
+ * kernels.  The dispatcher deals workgroups to the 8 XCDs round robin whatever the mask says, so a mask should hold the same number of
+ * CUs of every XCD (helpers/runtime.balanced_cu_mask). */
+int l3c_stream_create_cu_mask(const uint32_t *mask_host, int n_words, l3c_stream_t *stream_out_host);
 int l3c_stream_destroy(l3c_stream_t stream);
 
 /* ---- arithmetic coder (replaces torchac.cpp) ---------------------------------------------------------------------- */
@@ -326,13 +330,6 @@ typedef struct {
     int stride;            /* 1, or 2 (KS == 5 only) */
     int dilation;          /* 1, 2 or 4 (KS == 3 only); padding is KS/2 when dilation == 1 else dilation */
     int epilogue;          /* L3C_EPI_* flags */
-    /* Images of DIFFERENT sizes in one batch ("canvas" batches, ABI version 2): device pointer to int32 [B][2] = (rows, cols) of image b in
-     * the coordinates of the convolution's output (before a pixel shuffle), or NULL (every image fills [Hout][Wout]).  The tensors keep
-     * their rectangular [B][H][W][C] canvas layout; a kernel that honours out_dims never STORES an output pixel outside its image's bounds
-     * (and skips the work), so a canvas that was zero outside the images stays zero there -- which is exactly the zero padding the next
-     * 3x3 layer needs when it reads across an image's border.  Honoured by l3c_conv_wino4 / _phase / _stride2; l3c_conv_pw ignores it
-     * (1x1: pixels outside the images hold values nobody reads); l3c_conv_mfma / l3c_conv_direct reject a non-NULL pointer. */
-    const int *out_dims;
 } l3c_conv_desc;
 
 /* fp32 implicit-GEMM convolution on v_mfma_f32_32x32x2_f32; Cin % 16 == 0 (64 or 192 on this path). */
@@ -388,12 +385,10 @@ int l3c_conv_direct(const l3c_conv_desc *desc_host, l3c_stream_t stream);
  * conv 3x3 3->Cf, zero padding applied to the mean-shifted image.  (multiscale_network.py:241, head.py:26-41)
  *   w1,b1  sub_rgb_mean [3][3],[3];  w2,b2 heads.0.head.0 [3][3],[3];  w3 [Cf][3][3][3], b3 [Cf];  out pixel-major
  * shifted_out (may be NULL): planar [B][3][H][W], the input of the 3x3 conv, for stage-wise parity tests.
- * img_dims (may be NULL): canvas batches, see l3c_conv_desc.out_dims -- int32 [B][2] (rows, cols) of image b inside the [H][W] canvas:
- * the conv's zero padding starts at the IMAGE's border and nothing is stored outside it.
  */
 int l3c_rgb_head(const float *img, const float *w1, const float *b1, const float *w2, const float *b2,
                  const float *w3, const float *b3, int B, int H, int W, int Cf, float *out, float *shifted_out,
-                 const int *img_dims, l3c_stream_t stream);
+                 l3c_stream_t stream);
 
 /*
  * Encoder output: 1x1 conv Cf -> C (`to_q`, net.py:113-121) fused with the hard quantiser (quantizer.py:72-87:
@@ -409,11 +404,9 @@ int l3c_to_q_quantize(const float *feat, const float *w, const float *b, const f
  *   bn_q planar [B][C][HW]; w [Cf][C], b [Cf]; fuse pixel-major [B][HW][Cf] or NULL; out pixel-major [B][HW][Cf]
  *   Limits: C <= 8 (the bottleneck's weights live in registers; q.C is 5 or 3 in every shipped config), Cf % 4 == 0 and
  *   256 % (Cf / 4) == 0, HW < 2^31.  Anything else returns L3C_ERR_INVALID_ARG.
- *   img_dims (may be NULL) + canvas_w: canvas batches (l3c_conv_desc.out_dims) -- HW = rows x canvas_w, pixels outside image b's
- *   (rows, cols) are not stored.
  */
 int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float *fuse, int64_t B, int64_t HW, int C,
-                 int Cf, float *out, const int *img_dims, int canvas_w, l3c_stream_t stream);
+                 int Cf, float *out, l3c_stream_t stream);
 
 /*
  * RGB baselines (BicubicSubsampling encoder, modules/net.py:65-80): the reference leaves the GPU for PIL's BICUBIC resize

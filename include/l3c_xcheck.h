@@ -30,6 +30,16 @@ int l3c_conv_wino(const l3c_conv_desc *desc_host, l3c_stream_t stream);
 int l3c_conv_wino_set_tiles_per_block(int n);
 
 /*
+ * PROBE (round 6; csrc/conv_wino4w.hip): Winograd F(4x4,3x3) on v_mfma_f32_32x32x2_f32 -- a wavefront owns 9 of the 36 positions for 32
+ * tiles x 32 channels, four wavefronts cover the positions, M is exchanged through LDS for the output transform -- built to MEASURE the
+ * decomposition the round-5 verdict asked about against the product's conv_wino4_kernel (16x16x4 MFMA, all 36 positions per wavefront,
+ * output transform in registers).  3x3, stride 1, dilation 1, Cout <= 64, Cin % 16 == 0, bias (+ L3C_EPI_RELU).
+ */
+int64_t l3c_conv_wino4w_packed_words(int Cout, int Cin);
+int l3c_conv_wino4w_pack_weights(const float *w_oihw, int Cout, int Cin, float *packed, l3c_stream_t stream);
+int l3c_conv_wino4w(const l3c_conv_desc *desc_host, int tiles_per_block, l3c_stream_t stream);
+
+/*
  * csrc/dmll_core.h: sigmoid_sat (what the kernels evaluate) against 1 / (1 + expf(-a)) (what it has to equal) on every one of
  * the 2^32 float bit patterns.  *mismatches_dev (uint64, device, zeroed by the caller) += number of differing results,
  * *first_bad_dev (uint32, device, 0xFFFFFFFF from the caller) = smallest differing bit pattern.

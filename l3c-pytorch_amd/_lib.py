@@ -27,7 +27,7 @@ class ConvDesc(ctypes.Structure):
                 ('residual', c_vp), ('res_cstride', c_int), ('res_coff', c_int),
                 ('out', c_vp), ('out_cstride', c_int), ('out_coff', c_int),
                 ('B', c_int), ('Hin', c_int), ('Win', c_int), ('Cin', c_int), ('Cout', c_int),
-                ('KS', c_int), ('stride', c_int), ('dilation', c_int), ('epilogue', c_int), ('out_dims', c_vp)]
+                ('KS', c_int), ('stride', c_int), ('dilation', c_int), ('epilogue', c_int)]
 
 
 class AcGroup(ctypes.Structure):
@@ -73,6 +73,7 @@ PROTOTYPES = {
     'l3c_last_error': (ctypes.c_char_p, []),
     'l3c_device_info': (c_int, [ctypes.c_char_p, c_int, ctypes.POINTER(c_int), ctypes.c_char_p, c_int]),
     'l3c_stream_create_cu_range': (c_int, [c_int, c_int, ctypes.POINTER(c_vp)]),
+    'l3c_stream_create_cu_mask': (c_int, [ctypes.POINTER(ctypes.c_uint32), c_int, ctypes.POINTER(c_vp)]),
     'l3c_stream_destroy': (c_int, [c_vp]),
     'l3c_interval_words': (c_i64, [c_i64, c_i64]),
     'l3c_ac_intervals_from_table': (c_int, [c_vp, c_i64, c_int, c_vp, c_i64, c_i64, c_vp, c_vp]),
@@ -110,9 +111,9 @@ PROTOTYPES = {
     'l3c_conv_pw_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_pw': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_direct': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
-    'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
+    'l3c_rgb_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_vp, c_vp, c_vp]),
     'l3c_to_q_quantize': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp, c_vp, c_vp, c_vp]),
-    'l3c_dec_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp, c_int, c_vp]),
+    'l3c_dec_head': (c_int, [c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_vp, c_vp]),
     'l3c_meanshift_planar': (c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp]),
     'l3c_rgb_to_u8': (c_int, [c_vp, ctypes.POINTER(c_f32), c_i64, c_i64, c_vp, c_vp]),
     'l3c_resample_u8': (c_int, [c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp, c_vp, c_int, c_vp, c_vp]),
@@ -127,6 +128,9 @@ XCHECK_PROTOTYPES = {
     'l3c_conv_wino': (c_int, [ctypes.POINTER(ConvDesc), c_vp]),
     'l3c_conv_wino_set_tiles_per_block': (c_int, [c_int]),
     'l3c_xcheck_sigmoid_exhaustive': (c_int, [c_vp, c_vp, c_vp]),
+    'l3c_conv_wino4w_packed_words': (c_i64, [c_int, c_int]),
+    'l3c_conv_wino4w_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
+    'l3c_conv_wino4w': (c_int, [ctypes.POINTER(ConvDesc), c_int, c_vp]),
 }
 XCHECK_LIB_PATH = os.path.join(_HERE, 'csrc', 'libl3c_hip_xcheck.so')
 
@@ -217,6 +221,20 @@ def cu_range_stream(first_cu, n_cu):
     require_gpu()
     h = c_vp()
     call('l3c_stream_create_cu_range', first_cu, n_cu, ctypes.byref(h))
+    return torch.cuda.ExternalStream(h.value)
+
+
+def cu_mask_stream(cus):
+    """torch stream object whose kernels are confined to the compute units listed in `cus` (hipExtStreamCreateWithCUMask)."""
+    require_gpu()
+    _, n_cu, _ = device_info()
+    words = (ctypes.c_uint32 * ((n_cu + 31) // 32))()
+    for cu in cus:
+        if not 0 <= cu < n_cu:
+            raise L3CError('compute unit {} outside the device ({} CUs)'.format(cu, n_cu))
+        words[cu >> 5] |= 1 << (cu & 31)
+    h = c_vp()
+    call('l3c_stream_create_cu_mask', words, len(words), ctypes.byref(h))
     return torch.cuda.ExternalStream(h.value)
 
 

@@ -334,32 +334,6 @@ class Bitcoding(object):
             enc.pending.append((C, Hs, Ws, iv))
         return enc
 
-    def prepare_canvas(self, x, dims):
-        """`prepare_batch` for images of DIFFERENT sizes that share one forward pass (MultiscaleNetwork.forward_canvas): x (B,3,Hc,Wc)
-        canvas, image b in its top-left dims[b] = (H_b, W_b) corner, zero elsewhere.  -> one EncodedBatch per image (batch size 1, its own
-        shape), from that image's slices of the canvas-shaped symbols and P: byte for byte the files of the image coded alone."""
-        net = self.blueprint.net
-        if self.auto_recurse:      # forward_canvas returns `scales` predictions and never applies the recursion (RGB baselines: prepare_batch)
-            raise NotImplementedError('canvas batches are not provided for auto_recurse > 0')
-        sym, P, _ = net.forward_canvas(x.to('cuda', torch.float32), dims)
-        assert len(P) == self.n_predicted_scales(), (len(P), self.n_predicted_scales())
-        K = net.config_ms.prob.K
-        encs = []
-        for b, (H, W) in enumerate(dims):
-            enc = EncodedBatch(1, (H, W))
-            for scale, dmll, uniform in self.iter_scale_dmll():
-                hs, ws = H >> scale, W >> scale
-                s_b = sym[scale][b:b + 1, :, :hs, :ws].contiguous()
-                C = s_b.shape[1]
-                if uniform:
-                    iv = ops.intervals_from_table(self._uniform_row(dmll.L), s_b.reshape(C, hs * ws), C, hs * ws, broadcast_row=True)
-                else:
-                    P_b = P[scale][b:b + 1, :hs, :ws, :].contiguous()
-                    iv = ops.dmll_encode_intervals(P_b, s_b, self._targets(dmll), C, K, dmll.rgb_scale)
-                enc.pending.append((C, hs, ws, iv))
-            encs.append(enc)
-        return encs
-
     def code(self, batches):
         """Second half: ONE grouped range-coder launch (l3c_ac_encode_groups) over every scale of every prepared batch
         -- all their streams are coded concurrently, whatever the image sizes -- on a side stream that the current
@@ -399,9 +373,7 @@ class Bitcoding(object):
     N_CODER_GROUPS = 4
 
     def encode_many(self, batches, upload=None, on_group=None, n_groups=None, weights=None):
-        """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries), or -- through `upload` -- entries that turn
-        into (canvas, dims) pairs: images of DIFFERENT sizes sharing one forward pass (prepare_canvas).  -> list, in the order given,
-        of EncodedBatch (a list of one EncodedBatch per image for a canvas entry).
+        """batches: list of (B_i,3,H_i,W_i) tensors (shapes may differ between entries).  -> list, in the order given, of EncodedBatch.
         Small batches leave most of the machine idle (one 768x512 image is 192 tiles at the first scale, 12 at the
         coarsest, for 256 CUs) and their serial coder chains are as long as ever, so
           * the forward passes + heads of different batches run on N_FORWARD_STREAMS streams side by side, largest
@@ -440,8 +412,8 @@ class Bitcoding(object):
         result = [None] * len(batches)
         pending, coded = [], []
 
-        def flat(k):           # an entry's EncodedBatch objects: one, or one per image of a canvas entry
-            return result[k] if isinstance(result[k], list) else [result[k]]
+        def flat(k):
+            return [result[k]]
 
         def collect_finished(block):
             # oldest group first; without `block` only groups whose coder launch has COMPLETED (the host must never sit waiting for a
@@ -453,12 +425,9 @@ class Bitcoding(object):
             st = fwd[n % len(fwd)]
             with torch.cuda.stream(st):
                 x = batches[i] if upload is None else upload(batches[i])
-                dims = None
-                if isinstance(x, tuple):               # (canvas, [(H_b, W_b)]): images of different sizes in one pass
-                    x, dims = x
                 if x.is_cuda:
                     x.record_stream(st)
-                result[i] = self.prepare_batch(x) if dims is None else self.prepare_canvas(x, dims)
+                result[i] = self.prepare_batch(x)
                 ev = torch.cuda.Event()
                 ev.record(st)
             pending.append((i, ev))
@@ -475,12 +444,13 @@ class Bitcoding(object):
 
     @staticmethod
     def _collect(indices, result, on_group):
-        first = result[indices[0]][0] if isinstance(result[indices[0]], list) else result[indices[0]]
+        first = result[indices[0]]
         with torch.cuda.stream(first.coder_stream):
             on_group([(k, result[k]) for k in indices])
 
-    def decode_batch(self, files):
-        """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU,
+    def decode_batch(self, files, out_dtype=torch.int64):
+        """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU (the reference's
+        dtype, bitcoding.py:125-161; out_dtype: torch.uint8 / int16 for callers that want the pixels without the 8-byte form),
         list of padding tuples).
         Round 6: the host only parses the FRAMING (a few length fields per file, `parse_containers`); the files cross PCIe as they
         are, in one copy from a page-locked buffer, and one kernel (l3c_container_read) cuts every stream out of them in the
@@ -532,21 +502,75 @@ class Bitcoding(object):
             bn_prev = ops.sym_to_bn(sym, dmll.bin_width, dmll.x_min)
             if rgb_net and scale > 0:                  # BicubicDownsamplingEnc: the decoder is fed value - mean (net.py:72-80)
                 bn_prev = bn_prev - _rgb_mean_tensor(bn_prev.device)
-        return sym.to(torch.int64), parsed.padding
+        return sym.to(out_dtype), parsed.padding
 
-    def decode_many(self, batches, on_batch=None):
+    N_DECODE_LANES = 2
+
+    def _lanes(self, n, chain_cus):
+        """`n` pairs (main stream, side stream) for decode_many.  chain_cus > 0: every side stream -- the latency-bound range-decoder
+        chains -- is confined to `chain_cus` compute units (the same number of every XCD, helpers/runtime.balanced_cu_sets) and every main
+        stream -- convolutions, table kernels -- to the others, so that a lane's MFMA wavefronts never take the registers or the issue
+        slots of another lane's chains."""
+        key = (n, chain_cus)
+        if getattr(self, '_lane_key', None) != key:
+            from .. import _lib
+            if chain_cus:
+                from ..helpers import runtime
+                _, n_cu, _ = _lib.device_info()
+                chains, rest = runtime.balanced_cu_sets(n_cu, chain_cus)
+                self._lane_streams = [(_lib.cu_mask_stream(rest), _lib.cu_mask_stream(chains)) for _ in range(n)]
+            else:
+                self._lane_streams = [(torch.cuda.Stream(), torch.cuda.Stream()) for _ in range(n)]
+            self._lane_key = key
+        return self._lane_streams
+
+    def decode_many(self, batches, on_batch=None, lanes=None, chain_cus=0, out_dtype=torch.int64):
         """batches: list of lists of `.l3c` byte strings; the files of ONE entry are equally sized (padded) images (a forward pass of
         `encode_many`), entries may differ in shape.  -> list, in the order given, of ((B_i,3,H_i,W_i) int64 on the GPU, padding tuples),
-        or None per entry when `on_batch(index, pixels, padding)` consumes the results as they complete (then nothing is kept on the
-        device).  The reference decodes a folder one file after the other (bitcoding.py:125-161 per file, multiscale_tester.py:353-381
-        over the folder); here every entry is one `decode_batch`."""
+        or None per entry when `on_batch(index, pixels, padding)` consumes the results as they are enqueued (called under the stream
+        that decodes the entry; then nothing is kept on the device).  The reference decodes a folder one file after the other
+        (bitcoding.py:125-161 per file, multiscale_tester.py:353-381 over the folder).
+        STREAMING (round 6): entry i runs on lane i % lanes -- a main stream (get_P convolutions, bottleneck scales, RGB tables) and a side
+        stream (RGB chains) of its own -- so that the MFMA-bound convolutions of entry i + 1 run beside the latency-bound RGB chains
+        of entry i, which leave most of the machine idle (3 B wavefronts).  Within one entry the two cannot overlap: the chains need the
+        tables, the tables need P.  One host thread enqueues everything (an entry costs a few milliseconds of host time since the RGB
+        schedule is one library call); a lane's previous entry is waited for before its buffers are reused."""
+        n = self.N_DECODE_LANES if lanes is None else int(lanes)
         result = [None] * len(batches)
+        if n <= 1 or len(batches) <= 1:
+            for i, files in enumerate(batches):
+                pixels, padding = self.decode_batch(files, out_dtype)
+                if on_batch is not None:
+                    on_batch(i, pixels, padding)
+                else:
+                    result[i] = (pixels, padding)
+            return result
+        self.blueprint.net._prepare()                  # pack the weights before forking streams
+        outer = torch.cuda.current_stream()
+        start = torch.cuda.Event()
+        start.record(outer)
+        lane_streams = self._lanes(n, chain_cus)
+        done = [None] * n
         for i, files in enumerate(batches):
-            pixels, padding = self.decode_batch(files)
-            if on_batch is not None:
-                on_batch(i, pixels, padding)
-            else:
-                result[i] = (pixels, padding)
+            main, side = lane_streams[i % n]
+            if i < n:
+                main.wait_event(start)
+            with torch.cuda.stream(main):
+                self._lane_side = side
+                try:
+                    pixels, padding = self.decode_batch(files, out_dtype)
+                finally:
+                    self._lane_side = None
+                if on_batch is not None:
+                    on_batch(i, pixels, padding)
+                else:
+                    pixels.record_stream(outer)
+                    result[i] = (pixels, padding)
+                done[i % n] = torch.cuda.Event()
+                done[i % n].record(main)
+        for ev in done:
+            if ev is not None:
+                outer.wait_event(ev)
         return result
 
     def _decode_z_scale(self, P, targets, streams, B, C, K, H, W):
@@ -612,7 +636,7 @@ class Bitcoding(object):
         overlap = B >= 16 if self.decode_overlap is None else bool(self.decode_overlap)
         mode = {'never': 0, 'auto': 1, 'always': 2}[self.rgb_window]
         ws, stats = ops.decode_rgb(P, targets, sym, buf, offs, lens, bounds, K, 2 if overlap else 1, mode,
-                                   self._side_stream() if overlap else None)
+                                   (getattr(self, '_lane_side', None) or self._side_stream()) if overlap else None)
         self.last_rgb_window_stats = stats      # (development / tests: misses per channel, chunk + 2, image)
         return sym
 

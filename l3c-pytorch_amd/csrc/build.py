@@ -13,14 +13,15 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ['l3c_api.hip', 'ac_kernels.hip', 'dmll_kernels.hip', 'conv_mfma.hip', 'conv_small.hip', 'container.hip', 'conv_pw.hip', 'conv_wino4.hip', 'decode_pipeline.hip']
 # test-only second library (include/l3c_xcheck.h): the round-1/2 Winograd F(2x2,3x3) kernel, an independent implementation the tests
 # compare the product's kernels with.  The product library does not contain it and the package never loads it outside the tests.
-XCHECK_SOURCES = ['l3c_api.hip', 'conv_wino.hip', 'xcheck_dmll.hip']
+XCHECK_SOURCES = ['l3c_api.hip', 'conv_wino.hip', 'xcheck_dmll.hip', 'conv_wino4w.hip']
 HEADERS = ['ac_core.h', 'dmll_core.h', 'l3c_common.h', os.path.join('..', '..', 'include', 'l3c_hip.h'), os.path.join('..', '..', 'include', 'l3c_xcheck.h')]
 LIB = os.path.join(HERE, 'libl3c_hip.so')
 XCHECK_LIB = os.path.join(HERE, 'libl3c_hip_xcheck.so')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function']
 # per-source flags.  The MFMA kernels: no SLP vectorisation -- hipcc otherwise packs adjacent scalar fp32 adds of the input
 # transform into v_pk_add_f32 / v_pk_fma_f32, which beside MFMAs cost more issue time than the plain instructions they replace.
-SOURCE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_pw.hip': ['-fno-slp-vectorize'], 'conv_wino4.hip': ['-fno-slp-vectorize']}
+SOURCE_FLAGS = {'conv_wino.hip': ['-fno-slp-vectorize'], 'conv_pw.hip': ['-fno-slp-vectorize'], 'conv_wino4.hip': ['-fno-slp-vectorize'],
+                'conv_wino4w.hip': ['-fno-slp-vectorize']}
 
 
 def _stale(target, deps):

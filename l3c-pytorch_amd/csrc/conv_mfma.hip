@@ -639,7 +639,6 @@ int l3c_conv_mfma(const l3c_conv_desc *d, l3c_stream_t stream) {
     ConvParams p;
     const int rc = fill_params(d, p);
     if (rc != L3C_OK) return rc;
-    L3C_REQUIRE(!d->out_dims, "canvas batches (out_dims) are not provided by the implicit-GEMM kernel");
     L3C_REQUIRE(d->Cin % 16 == 0, "Cin must be a multiple of 16");
     hipStream_t s = l3c::as_stream(stream);
 #ifdef L3C_DEV_PROBES
@@ -667,7 +666,6 @@ int l3c_conv_direct(const l3c_conv_desc *d, l3c_stream_t stream) {
     ConvParams p;
     const int rc = fill_params(d, p);
     if (rc != L3C_OK) return rc;
-    L3C_REQUIRE(!d->out_dims, "canvas batches (out_dims) are not provided by the cross-check kernel");
     const int64_t total = (int64_t)p.B * p.Hout * p.Wout * p.Cout;
     int64_t g = (total + 255) / 256;
     hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, l3c::as_stream(stream), p,

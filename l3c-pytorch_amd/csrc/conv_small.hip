@@ -20,8 +20,7 @@ __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__
                                                        const float *__restrict__ b1, const float *__restrict__ w2,
                                                        const float *__restrict__ b2, const float *__restrict__ w3,
                                                        const float *__restrict__ b3, int H, int W, int Cf,
-                                                       float *__restrict__ out, float *__restrict__ shifted_out,
-                                                       const int *__restrict__ dims) {
+                                                       float *__restrict__ out, float *__restrict__ shifted_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *s_w = smem;                                   // [27][Cf]  (tap-major: (ky*3+kx)*3 + ci)
     float *s_in = smem + 27 * Cf;                        // [3][RH_TH+2][RH_TW+2]
@@ -47,9 +46,7 @@ __global__ __launch_bounds__(256) void rgb_head_kernel(const float *__restrict__
     const f32x4 bias = *reinterpret_cast<const f32x4 *>(&b3[q * 4]);
     const size_t plane = (size_t)H * W;
     const float *im = img + (size_t)b * 3 * plane;
-    // canvas batches (l3c_conv_desc.out_dims): image b fills (Hb, Wb) of the [H][W] canvas; the zero padding of the 3x3 conv starts at ITS
-    // border (the mean shifts carry biases: a canvas pixel outside the image is not a zero of the shifted image), nothing is stored outside
-    const int Hb = dims ? dims[2 * b] : H, Wb = dims ? dims[2 * b + 1] : W;
+    const int Hb = H, Wb = W;
     if (ox0 >= Wb) return;
     for (int nt = 0; nt < RH_NT; ++nt) {
         const int oy0 = (blockIdx.y * RH_NT + nt) * RH_TH;
@@ -235,8 +232,7 @@ __global__ __launch_bounds__(TQ_PIX) void to_q_quantize_tile_kernel(const float 
 constexpr int DH_MAX_C = 8;
 __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__ bn_q, const float *__restrict__ w,
                                                        const float *__restrict__ bias, const float *__restrict__ fuse,
-                                                       int64_t B, int64_t HW, int C, int Cf, float *__restrict__ out,
-                                                       const int *__restrict__ dims, int canvas_w) {
+                                                       int64_t B, int64_t HW, int C, int Cf, float *__restrict__ out) {
     const int quads = Cf / 4;
     const int q = threadIdx.x % quads, pl = threadIdx.x / quads, ppb = 256 / quads;
     const int64_t b = blockIdx.y;
@@ -250,13 +246,7 @@ __global__ __launch_bounds__(256) void dec_head_kernel(const float *__restrict__
     const float *fuse_b = fuse ? fuse + b * HW * Cf + q * 4 : nullptr;
     float *out_b = out + b * HW * Cf + q * 4;
     const int hw = (int)HW;
-    // canvas batches: pixels of the [HW / canvas_w][canvas_w] canvas outside image b's (rows, cols) are not stored (they stay zero)
-    const int Hb = dims ? dims[2 * b] : 0, Wb = dims ? dims[2 * b + 1] : 0;
     for (int64_t n = (int64_t)blockIdx.x * ppb + pl; n < hw; n += (int64_t)gridDim.x * ppb) {   // (hw may approach 2^31)
-        if (dims) {
-            const int y = (int)(n / canvas_w), x = (int)(n - (int64_t)y * canvas_w);
-            if (y >= Hb || x >= Wb) continue;
-        }
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < DH_MAX_C; ++c) {
@@ -353,14 +343,14 @@ int grid_1d(int64_t total, int block) {
 extern "C" {
 
 int l3c_rgb_head(const float *img, const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
-                 const float *b3, int B, int H, int W, int Cf, float *out, float *shifted_out, const int *img_dims, l3c_stream_t stream) {
+                 const float *b3, int B, int H, int W, int Cf, float *out, float *shifted_out, l3c_stream_t stream) {
     L3C_REQUIRE(img && w1 && b1 && w2 && b2 && w3 && b3 && out, "null pointer");
     L3C_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0, "bad shape");
     L3C_REQUIRE(Cf % 4 == 0 && Cf >= 4 && Cf <= 256 && 256 % (Cf / 4) == 0, "Cf must be 4 * a divisor of 256");
     const size_t lds = (size_t)(27 * Cf + 3 * (RH_TH + 2) * (RH_TW + 2)) * sizeof(float);
     const dim3 grid((unsigned)((W + RH_TW - 1) / RH_TW), (unsigned)((H + RH_TH * RH_NT - 1) / (RH_TH * RH_NT)), (unsigned)B);
     hipLaunchKernelGGL(rgb_head_kernel, grid, dim3(256), lds, l3c::as_stream(stream), img, w1, b1, w2, b2, w3, b3, H, W,
-                       Cf, out, shifted_out, img_dims);
+                       Cf, out, shifted_out);
     return l3c::check_launch("rgb_head_kernel");
 }
 
@@ -383,16 +373,15 @@ int l3c_to_q_quantize(const float *feat, const float *w, const float *b, const f
 }
 
 int l3c_dec_head(const float *bn_q, const float *w, const float *b, const float *fuse, int64_t B, int64_t HW, int C,
-                 int Cf, float *out, const int *img_dims, int canvas_w, l3c_stream_t stream) {
+                 int Cf, float *out, l3c_stream_t stream) {
     L3C_REQUIRE(bn_q && w && b && out, "null pointer");
-    L3C_REQUIRE(!img_dims || (canvas_w > 0 && HW % canvas_w == 0), "canvas batches: HW must be rows x canvas_w");
     L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && HW < (1ll << 31) && C > 0 && C <= DH_MAX_C, "bad shape (C <= 8, one image < 2^31 pixels)");
     L3C_REQUIRE(Cf % 4 == 0 && Cf >= 4 && Cf <= 1024 && 256 % (Cf / 4) == 0, "Cf must be 4 * a divisor of 256");
     const int64_t ppb = 256 / (Cf / 4);
     int64_t gx = (HW + ppb - 1) / ppb;
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(dec_head_kernel, dim3((unsigned)gx, (unsigned)B), dim3(256), 0, l3c::as_stream(stream), bn_q,
-                       w, b, fuse, B, HW, C, Cf, out, img_dims, canvas_w);
+                       w, b, fuse, B, HW, C, Cf, out);
     return l3c::check_launch("dec_head_kernel");
 }
 

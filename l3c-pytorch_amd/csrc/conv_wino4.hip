@@ -73,7 +73,6 @@ struct Wino4Params {
     int tiles_x, tiles_y, n_chunks_o, total_blocks;
     int tpb, groups_x;
     unsigned long long *dbg;   // development (-DL3C_W4_TIMELINE): per-wavefront s_memtime stamps, nullptr otherwise
-    const int *dims;           // canvas batches: per-image (rows, cols) of the OUTPUT, or nullptr (l3c_conv_desc.out_dims)
 };
 
 constexpr int OT = 16;                          // output tile of a block: 4 x 4 Winograd tiles of 4 x 4 pixels
@@ -213,18 +212,8 @@ __global__ __launch_bounds__(256, 2) void conv_wino4_kernel(const Wino4Params p)
     const unsigned t_y = p.div_groups_x.div(grp);
     const int sy0 = (int)t_y * OT;                                         // tile row origin in sub-grid coordinates
     const int tx_first = (int)(grp - t_y * (unsigned)p.groups_x) * p.tpb;  // first tile of this block
-    // Canvas batches (images of different sizes in one launch): image b only fills (Ho_b, Wo_b) of the [Ho][Wo] canvas.  Nothing is ever
-    // stored outside it -- the canvas stays zero there, which is the zero padding the patch fetch of the next layer reads -- and blocks /
-    // tiles that lie outside do not run.  (Uniform per block: the whole block leaves before its first barrier.)
-    int Ho_b = p.Ho, Wo_b = p.Wo, tiles_x_b = p.tiles_x;
-    if (p.dims) {
-        Ho_b = __builtin_amdgcn_readfirstlane(p.dims[2 * b]);
-        Wo_b = __builtin_amdgcn_readfirstlane(p.dims[2 * b + 1]);
-        const int sub_w = Wo_b > px ? (Wo_b - px + dil - 1) >> dl : 0;    // columns of this sub-grid inside the image
-        tiles_x_b = (sub_w + OT - 1) / OT;
-        if (py + dil * sy0 >= Ho_b || tx_first >= tiles_x_b) return;
-    }
-    const int n_t = min(p.tpb, tiles_x_b - tx_first);
+    const int Ho_b = p.Ho, Wo_b = p.Wo;
+    const int n_t = min(p.tpb, p.tiles_x - tx_first);
 
     // ---- patch fetch: thread (r0 = tid / 36 < 6, column c = tid % 36 / 2, half = tid & 1) fetches the 16-byte pieces (channels
     // 4 half .. + 3 of the chunk) of the patch pixels (r0 + 6 k, c), k = 0..2: ONE per-lane byte offset, the rows 6 apart by a
@@ -813,7 +802,6 @@ static int conv_wino4_launch(const l3c_conv_desc *d, int poly, int phase_y, int 
     L3C_REQUIRE(S2 * 20 * p.dil * (p.W + 64 * p.dil) * p.out_cstride * 4 < 0x7ffffff0ll && 20ll * p.dil * (p.W + 64 * p.dil) * p.res_cstride * 4 < 0x7ffffff0ll,
                 "image too wide for 32-bit offsets inside a tile row");
     p.total_blocks = (int)total;
-    p.dims = d->out_dims;
 #ifdef L3C_W4_TIMELINE
     p.dbg = g_w4_dbg;
 #endif

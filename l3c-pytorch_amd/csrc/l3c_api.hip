@@ -56,6 +56,15 @@ int l3c_stream_create_cu_range(int first_cu, int n_cu, l3c_stream_t *stream_out_
     return L3C_OK;
 }
 
+int l3c_stream_create_cu_mask(const uint32_t *mask_host, int n_words, l3c_stream_t *stream_out_host) {
+    L3C_REQUIRE(mask_host && stream_out_host && n_words > 0 && n_words <= 32, "bad mask");
+    hipStream_t st = nullptr;
+    const int rc = l3c::check_hip(hipExtStreamCreateWithCUMask(&st, (uint32_t)n_words, mask_host), "hipExtStreamCreateWithCUMask");
+    if (rc != L3C_OK) return rc;
+    *stream_out_host = reinterpret_cast<l3c_stream_t>(st);
+    return L3C_OK;
+}
+
 int l3c_stream_destroy(l3c_stream_t stream) {
     return l3c::check_hip(hipStreamDestroy(l3c::as_stream(stream)), "hipStreamDestroy");
 }

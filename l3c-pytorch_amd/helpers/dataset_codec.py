@@ -68,35 +68,7 @@ def plan_set(shapes, order, max_batch, fac):
     return chunks, padded, pads, len(groups)
 
 
-def plan_canvases(shapes, order, max_batch, fac, max_waste=0.25):
-    """Host-side plan for passes that may hold images of DIFFERENT padded shapes (MultiscaleNetwork.forward_canvas): the images are
-    sorted by (aspect class, height) and cut greedily into passes of at most max_batch whose canvas -- the bounding box of the pass's
-    padded shapes -- wastes at most max_waste of its area.  Same return value as plan_set; a pass of equal shapes is a plain batch."""
-    pads, padded_of = {}, {}
-    for i in order:
-        h, w = shapes[i]
-        pads[i] = pad.padding_for(h, w, fac)
-        padded_of[i] = (h + pads[i][2] + pads[i][3], w + pads[i][0] + pads[i][1])
-    ranked = sorted(order, key=lambda i: (round(padded_of[i][1] / float(padded_of[i][0]), 1), padded_of[i][0], padded_of[i][1], i))
-    chunks, canvas = [], []
-    cur, ch, cw, area = [], 0, 0, 0
-    for i in ranked:
-        h, w = padded_of[i]
-        nh, nw = max(ch, h), max(cw, w)
-        if cur and (len(cur) >= max_batch or nh * nw * (len(cur) + 1) > (1.0 + max_waste) * (area + h * w)):
-            chunks.append(cur)
-            canvas.append((ch, cw))
-            cur, ch, cw, area = [], 0, 0, 0
-            nh, nw = h, w
-        cur.append(i)
-        ch, cw, area = nh, nw, area + h * w
-    if cur:
-        chunks.append(cur)
-        canvas.append((ch, cw))
-    return chunks, canvas, pads, len(set(padded_of.values())), padded_of
-
-
-def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8, canvas=False, max_waste=0.25):
+def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8):
     """imgs: {index: uint8 (3,H,W) HOST tensor}; order: the indices to code.  -> ({index: `.l3c` bytes}, number of distinct
     padded shapes, number of forward passes).  `marks` (dict) receives host time stamps of the stages.  n_pinned: page-locked staging
     buffers of this process (helpers/sharding.host_budget: fewer per rank when several ranks share a host).
@@ -127,15 +99,10 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
             raise ValueError('encode_set: image {} must be a contiguous host uint8 (3,H,W) tensor, got {} {} on {}'.format(
                 i, t.dtype, tuple(t.shape), t.device))
     shapes = {i: tuple(imgs[i].shape[-2:]) for i in order}
-    # canvas: images of different padded shapes share a pass (MultiscaleNetwork.forward_canvas; round 4).  The files are byte-identical and
-    # the passes 3-6x fewer, but it is OFF by default: [measured, profiles/r04_canvas_passes.log] 200 images 117.5 vs 116.7 MPix/s, 500 images
-    # 122.6 vs 146.9 -- with three forward streams the GPU is already > 90 % busy on the small passes, and a canvas pass pays for its empty
-    # margin (13-15 % of the area: fills, the per-pixel layers) and for slicing every image's P out of the canvas
-    if canvas:
-        chunks, padded, pads, n_shapes, padded_of = plan_canvases(shapes, order, max_batch, fac, max_waste)
-    else:
-        chunks, padded, pads, n_shapes = plan_set(shapes, order, max_batch, fac)
-        padded_of = {i: padded[ci] for ci, c in enumerate(chunks) for i in c}
+    # (Round 4 also built passes that hold images of DIFFERENT padded shapes -- "canvas" batches: byte-identical files in 3-6x fewer passes, but
+    # no faster [measured, profiles/r04_canvas_passes.log: 200 images 117.5 vs 116.7 MPix/s, 500 images 122.6 vs 146.9]: with three forward
+    # streams the GPU is already > 90 % busy on the small passes.  Removed in round 6; the code is in the history, DESIGN_HISTORY.md.)
+    chunks, padded, pads, n_shapes = plan_set(shapes, order, max_batch, fac)
     mark('plan (host)')
     ring = getattr(bc, '_h2d_ring', None)
     if ring is None:
@@ -165,10 +132,9 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
     def to_device(chunk, sizes, Hp, Wp, k, stage):
         dev = stage.cuda(non_blocking=True)
         ring.sent(k)
-        same = all(padded_of[i] == (Hp, Wp) for i in chunk)
-        if same and not any(any(pads[i]) for i in chunk):
+        if not any(any(pads[i]) for i in chunk):
             return dev.view(len(chunk), 3, Hp, Wp)
-        # zero padding of every image AND, for a canvas pass, the zero margin around the smaller images: written on the device
+        # zero padding of every image: written on the device
         x = torch.zeros((len(chunk), 3, Hp, Wp), dtype=torch.uint8, device='cuda')
         off = 0
         for b, (i, n) in enumerate(zip(chunk, sizes)):
@@ -176,21 +142,15 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
             left, _, top, _ = pads[i]
             x[b, :, top:top + h, left:left + w] = dev[off:off + n].view(3, h, w)
             off += n
-        return x if same else (x, [padded_of[i] for i in chunk])
+        return x
 
     def on_group(group):
         t0 = time.perf_counter()
         encs, pad_lists, owners = [], [], []
         for ci, enc in group:
-            if isinstance(enc, list):          # a canvas pass: one EncodedBatch (of one image) per image
-                for i, e in zip(chunks[ci], enc):
-                    encs.append(e)
-                    pad_lists.append([pads[i]])
-                    owners.append([i])
-            else:
-                encs.append(enc)
-                pad_lists.append([pads[i] for i in chunks[ci]])
-                owners.append(chunks[ci])
+            encs.append(enc)
+            pad_lists.append([pads[i] for i in chunks[ci]])
+            owners.append(chunks[ci])
         for idxs, fs in zip(owners, EncodedBatch.many_to_bytes(encs, pad_lists)):
             for i, f in zip(idxs, fs):
                 files[i] = f
@@ -231,12 +191,12 @@ def plan_decode_set(files, order, max_batch):
     return chunks, padded
 
 
-def decode_set(bc, files, order, max_batch=16, marks=None):
+def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus=0, n_pinned=4):
     """files: {index: `.l3c` bytes} (as `encode_set` returns them); order: the indices to decode.  -> {index: uint8 (3,H,W) HOST tensor},
     the padding undone.  The mirror of `encode_set` for the reference's folder evaluation, which decodes EVERY file it wrote and
     compares it with the input (multiscale_tester.py:353-381, assert_equal at :373): files of equal padded shape share a batch,
-    largest batches first, every batch through `Bitcoding.decode_many`; the decoded pixels leave the device as uint8 through a
-    page-locked buffer per batch while the next batch decodes."""
+    largest batches first, the batches stream through `Bitcoding.decode_many` (batch i + 1's convolutions beside batch i's RGB chains);
+    the decoded pixels leave the device as uint8 through `n_pinned` page-locked buffers while later batches decode."""
     import time
     from . import pad as _pad
 
@@ -248,9 +208,13 @@ def decode_set(bc, files, order, max_batch=16, marks=None):
     by_size = sorted(range(len(chunks)), key=lambda k: -len(chunks[k]) * padded[k][0] * padded[k][1])
     mark('plan (host)')
     out, pending = {}, []
+    ring = getattr(bc, '_d2h_ring', None)
+    if ring is None or len(ring) != n_pinned:
+        ring = bc._d2h_ring = [None] * n_pinned
+    turn = [0]
 
-    def collect(block):
-        while pending and (block or pending[0][2].query()):
+    def collect(block, keep=0):
+        while len(pending) > keep and (block or pending[0][2].query()):
             ci, host, ev, paddings = pending.pop(0)
             ev.synchronize()
             for k, i in enumerate(chunks[ci]):
@@ -261,15 +225,20 @@ def decode_set(bc, files, order, max_batch=16, marks=None):
 
     def on_batch(n, pixels, paddings):
         ci = by_size[n]
-        u8 = pixels.to(torch.uint8)                       # 0..255 by construction (symbols of a 256-symbol alphabet)
-        host = torch.empty(u8.shape, dtype=torch.uint8, pin_memory=True)
+        u8 = pixels                                       # uint8: 0..255 by construction (symbols of a 256-symbol alphabet)
+        collect(True, keep=n_pinned - 1)                  # the buffer about to be reused must have been read out
+        k = turn[0] = (turn[0] + 1) % n_pinned
+        if ring[k] is None or ring[k].numel() < u8.numel():
+            ring[k] = torch.empty(max(u8.numel(), 16 << 20), dtype=torch.uint8, pin_memory=True)
+        host = ring[k][:u8.numel()].view(u8.shape)
         host.copy_(u8, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         pending.append((ci, host, ev, paddings))
         collect(False)
 
-    bc.decode_many([[files[i] for i in chunks[ci]] for ci in by_size], on_batch=on_batch)
+    bc.decode_many([[files[i] for i in chunks[ci]] for ci in by_size], on_batch=on_batch, lanes=lanes, chain_cus=chain_cus,
+                   out_dtype=torch.uint8)
     collect(True)
     mark('parse + H2D + decode + D2H (pipelined)')
     return out

@@ -195,44 +195,34 @@ class MultiscaleNetwork(nn.Module):
     # -- building blocks ------------------------------------------------------------------------------------------------
 
     @staticmethod
-    def _body(x, blocks, tail, canvas=None):
-        """8 x ResBlock(conv-ReLU-conv, += input) + conv, + global skip (edsr.py:83-86, net.py:142 / :181).
-        canvas (images of different sizes in the batch, ops.Canvas): every activation must be zero outside its image, so the body
-        walks three zero-filled buffers (t, and two that take turns as a block's input and output) instead of allocating one per
-        layer: three fills per body instead of seventeen."""
+    def _body(x, blocks, tail):
+        """8 x ResBlock(conv-ReLU-conv, += input) + conv, + global skip (edsr.py:83-86, net.py:142 / :181)."""
         skip = x
-        if canvas is None:
-            for c1, c2 in blocks:
-                t = ops.conv(x, c1, relu=True)
-                x = ops.conv(t, c2, residual=x)
-            return ops.conv(x, tail, residual=skip)
-        t = torch.zeros_like(x)
-        turn = [torch.zeros_like(x), torch.zeros_like(x)]
-        for i, (c1, c2) in enumerate(blocks):
-            ops.conv(x, c1, relu=True, out=t, canvas=canvas)
-            x = ops.conv(t, c2, residual=x, out=turn[i & 1], canvas=canvas)
-        return ops.conv(x, tail, residual=skip, canvas=canvas)
+        for c1, c2 in blocks:
+            t = ops.conv(x, c1, relu=True)
+            x = ops.conv(t, c2, residual=x)
+        return ops.conv(x, tail, residual=skip)
 
-    def _encoder(self, inp, s, pk, want_bn=False, canvas=None):
+    def _encoder(self, inp, s, pk, want_bn=False):
         e = pk['enc'][s]
-        x = ops.conv(inp, e['down'], canvas=canvas)
-        F = self._body(x, e['blocks'], e['tail'], canvas)
-        q = ops.to_q_quantize(F, e['to_q'][0], e['to_q'][1], e['levels'], want_bn=want_bn)    # (per pixel: values outside the images are never read)
+        x = ops.conv(inp, e['down'])
+        F = self._body(x, e['blocks'], e['tail'])
+        q = ops.to_q_quantize(F, e['to_q'][0], e['to_q'][1], e['levels'], want_bn=want_bn)
         return (F,) + tuple(q)
 
-    def _decoder(self, bn_q, fuse, s, pk, canvas=None):
+    def _decoder(self, bn_q, fuse, s, pk):
         d = pk['dec'][s]
-        x = ops.dec_head(bn_q, d['head'][0], d['head'][1], fuse, canvas=canvas)
-        x = self._body(x, d['blocks'], d['tail'], canvas)
-        return ops.conv(x, d['up'], pixel_shuffle=True, canvas=canvas)
+        x = ops.dec_head(bn_q, d['head'][0], d['head'][1], fuse)
+        x = self._body(x, d['blocks'], d['tail'])
+        return ops.conv(x, d['up'], pixel_shuffle=True)
 
-    def _prob(self, F, s, pk, canvas=None):
+    def _prob(self, F, s, pk):
         pr = pk['prob'][s]
         B, H, W, Cf = F.shape
-        cat = (torch.zeros if canvas is not None else torch.empty)(B, H, W, 3 * Cf, dtype=torch.float32, device=F.device)
+        cat = torch.empty(B, H, W, 3 * Cf, dtype=torch.float32, device=F.device)
         for i, a in enumerate(pr['atrous']):
-            ops.conv(F, a, out=cat, out_coff=i * Cf, canvas=canvas)
-        return ops.conv(cat, pr['lin'], canvas=canvas)
+            ops.conv(F, a, out=cat, out_coff=i * Cf)
+        return ops.conv(cat, pr['lin'])
 
     # -- reference API --------------------------------------------------------------------------------------------------
 
@@ -272,37 +262,6 @@ class MultiscaleNetwork(nn.Module):
             raw.F_dec.append(dec[s])
             out.append(EncOut(bn_q, bn_q, sym.long(), self.config_ms.q.L, F.permute(0, 3, 1, 2)), P.permute(0, 3, 1, 2))
         return out
-
-    def forward_canvas(self, x, dims):
-        """Images of DIFFERENT sizes in one pass (round 4; the reference codes one image per pass, multiscale_tester.py:272-351).
-        x: (B,3,Hc,Wc) float canvas, image b in its top-left (H_b, W_b) = dims[b] corner, ZERO elsewhere; every H_b, W_b a multiple of
-        2**num_scales.  -> (sym, P): per scale (finest first; sym has the image itself first) the canvas-shaped symbol planes
-        (B,C,Hs,Ws) int16 and P (B,Hs,Ws,Kp); inside image b's bounds they are bit for bit what forward() computes for that image
-        alone (tests/test_gpu_dataset.py::test_canvas_passes_code_the_same_files) -- outside they hold values nobody may read."""
-        _lib.require_gpu()
-        if self._rgb:
-            raise NotImplementedError('canvas batches are provided for the L3C model')
-        x = self._as_device_image(x)
-        fac = 2 ** self.scales
-        assert len(dims) == x.shape[0] and all(h % fac == 0 and w % fac == 0 and h <= x.shape[2] and w <= x.shape[3] for h, w in dims), dims
-        assert x.shape[2] == max(h for h, _ in dims) and x.shape[3] == max(w for _, w in dims), 'the canvas is the bounding box of its images'
-        pk = self._prepare()
-        cv = ops.Canvas(dims, x.device)
-        sym, P = [x.to(torch.int16)], []
-        inp = ops.rgb_head(x, pk['ms1'][0], pk['ms1'][1], pk['ms2'][0], pk['ms2'][1], pk['head0'][0], pk['head0'][1], canvas=cv)
-        enc = []
-        for s in range(self.scales):
-            if s:
-                inp = ops.conv(enc[-1][0], pk['heads'][s], canvas=cv)
-            enc.append(self._encoder(inp, s, pk, canvas=cv))
-        dec = [None] * self.scales
-        for s in reversed(range(self.scales)):
-            fuse = None if s == self.scales - 1 else dec[s + 1]
-            dec[s] = self._decoder(enc[s][2], fuse, s, pk, canvas=cv)
-        for s in range(self.scales):
-            sym.append(enc[s][1])
-            P.append(self._prob(dec[s], s, pk, canvas=cv))
-        return sym, P, cv
 
     def _forward_rgb(self, x, auto_recurse, pk):
         """RGB baselines (reference :226-306 with rgb_bicubic_baseline): identity heads, bicubic pyramid encoders

@@ -27,35 +27,6 @@ PROFILE_DETAIL = bool(os.environ.get('L3C_PROFILE_DETAIL'))   # split the keys b
 # 'direct' (plain-VALU cross-check in the product library), 'wino2' (the F(2x2,3x3) kernel of the TEST-ONLY libl3c_hip_xcheck.so).
 
 
-class Canvas(object):
-    """A batch of images of DIFFERENT sizes in one rectangular canvas (include/l3c_hip.h, l3c_conv_desc.out_dims): image b occupies
-    rows [0, H_b) x columns [0, W_b) of its [Hc][Wc] slot, every activation is zero outside its image, and the kernels that write
-    activations a 3x3 layer reads (conv_wino4, rgb_head, dec_head) never store outside -- so reading across an image's border reads
-    the zero padding the reference's convolution applies there, and the values INSIDE an image are bit for bit those of a batch of
-    that image alone.  dims: [(H_b, W_b)] at the finest scale, multiples of 2**num_scales; the coarser scales' bounds are the halves."""
-
-    def __init__(self, dims, device='cuda'):
-        self.dims = [(int(h), int(w)) for h, w in dims]
-        self.B = len(self.dims)
-        self.Hc, self.Wc = max(h for h, _ in self.dims), max(w for _, w in self.dims)
-        self.device = device
-        self._tables = {}
-
-    def table(self, rows):
-        """int32 [B][2] device tensor of every image's (rows, cols) on the canvas whose height is `rows` (Hc, Hc/2, Hc/4, ...)"""
-        if rows not in self._tables:
-            k = self.Hc // rows
-            assert rows * k == self.Hc and k & (k - 1) == 0, (rows, self.Hc)
-            assert all(h % k == 0 and w % k == 0 for h, w in self.dims), (self.dims, k)
-            t = torch.tensor([[h // k, w // k] for h, w in self.dims], dtype=torch.int32)
-            self._tables[rows] = t.to(self.device)
-        return self._tables[rows]
-
-    def dims_at(self, rows):
-        k = self.Hc // rows
-        return [(h // k, w // k) for h, w in self.dims]
-
-
 class PackedConv(object):
     """One conv layer resident on the device: OIHW weights, bias, and the packed copies of the kernels that can run it."""
 
@@ -125,25 +96,30 @@ class PackedConv(object):
             _lib.call_xcheck('l3c_conv_wino_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self._packed_wino2), stream())
         return self._packed_wino2
 
+    def packed_wino4w(self):
+        """tests / probes only ('wino4w'): the F(4x4,3x3) probe kernel on the 32x32x2 MFMA in the cross-check library (csrc/conv_wino4w.hip)"""
+        if getattr(self, '_packed_wino4w', None) is None:
+            assert self.KS == 3 and self.stride == 1 and self.dilation == 1 and self.Cin % 16 == 0 and self.Cout <= 64
+            n = _lib.load_xcheck().l3c_conv_wino4w_packed_words(self.Cout, self.Cin)
+            self._packed_wino4w = torch.empty(n, dtype=torch.float32, device='cuda')
+            _lib.call_xcheck('l3c_conv_wino4w_pack_weights', ptr(self.weight), self.Cout, self.Cin, ptr(self._packed_wino4w), stream())
+        return self._packed_wino4w
+
     def out_hw(self, H, W):
         pad = self.KS // 2 if self.dilation == 1 else self.dilation
         ext = (self.KS - 1) * self.dilation + 1
         return (H + 2 * pad - ext) // self.stride + 1, (W + 2 * pad - ext) // self.stride + 1
 
 
-def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, relu=False, pixel_shuffle=False, impl=None, canvas=None):
+def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, relu=False, pixel_shuffle=False, impl=None):
     """x: (B,H,W,cstride) pixel-major fp32.  Returns `out` ((B,Ho,Wo,Cout) freshly allocated when None).  impl: None = the
-    product's dispatch (see above); a name forces one kernel (tests, probes).  canvas: a Canvas -- images of different sizes in this
-    batch; a freshly allocated output is zero-filled, a given `out` must be zero outside the images already."""
+    product's dispatch (see above); a name forces one kernel (tests, probes)."""
     B, H, W, cstride = x.shape
     Ho, Wo = layer.out_hw(H, W)
     if out is None:
-        # (a 1x1 layer's output is read per pixel only: no fill -- P is the largest tensor of the path)
-        alloc = torch.zeros if canvas is not None and layer.KS != 1 else torch.empty
-        out = (alloc(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
-               else alloc(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
-    dims = canvas.table(Ho) if canvas is not None else None
-    assert impl in (None, 'wino4', 'wino2', 'gemm', 'poly5', 'poly5x4', 'direct'), impl
+        out = (torch.empty(B, 2 * Ho, 2 * Wo, layer.Cout // 4, dtype=torch.float32, device=x.device) if pixel_shuffle
+               else torch.empty(B, Ho, Wo, layer.Cout, dtype=torch.float32, device=x.device))
+    assert impl in (None, 'wino4', 'wino2', 'wino4w', 'gemm', 'poly5', 'poly5x4', 'direct'), impl
 
     # The Winograd kernel stores / loads 16 bytes per lane: channel strides and offsets of the output (and residual) slices must be
     # multiples of 4, the pointers 16-byte aligned, Cout a multiple of 4 (pixel shuffle: 16); it addresses one input image with
@@ -159,16 +135,25 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
                residual is None and not relu and not pixel_shuffle)
     if impl in ('poly5', 'poly5x4') or (impl is None and poly_ok):
         assert poly_ok, 'this layer / tensor has no polyphase form'
-        return _conv_poly5(x, layer, out, in_coff, out_coff, fused=impl != 'poly5x4', dims=dims)
+        return _conv_poly5(x, layer, out, in_coff, out_coff, fused=impl != 'poly5x4')
     if impl is None:
         kernel = ('wino4' if layer.packed_wino4 is not None and wino_ok else
                   'pw' if layer.packed_pw is not None and not (relu or pixel_shuffle or residual is not None) else 'gemm')
     else:
         kernel = impl
+    if kernel == 'wino4w':      # probe kernel of the test-only library: 3x3 / stride 1 / dilation 1, bias (+ ReLU)
+        assert layer.KS == 3 and layer.stride == 1 and layer.dilation == 1 and residual is None and not pixel_shuffle
+        d = ConvDesc()
+        d.inp, d.in_cstride, d.in_coff = ptr(x, torch.float32), cstride, in_coff
+        d.packed_w, d.bias = ptr(layer.packed_wino4w()), ptr(layer.bias)
+        d.out, d.out_cstride, d.out_coff = ptr(out, torch.float32), out.shape[-1], out_coff
+        d.B, d.Hin, d.Win, d.Cin, d.Cout = B, H, W, layer.Cin, layer.Cout
+        d.KS, d.stride, d.dilation = 3, 1, 1
+        d.epilogue = _lib.EPI_RELU if relu else 0
+        _lib.call_xcheck('l3c_conv_wino4w', d, int(os.environ.get('L3C_W4W_TPB', '0')), stream())
+        return out
     if kernel in ('wino4', 'wino2'):
         assert wino_ok and (kernel == 'wino2' or layer.packed_wino4 is not None), 'this layer / epilogue has no Winograd form'
-    if dims is not None and kernel not in ('wino4', 'pw'):
-        raise _lib.L3CError('canvas batches run on the Winograd and pointwise kernels only (this layer / tensor dispatches to {})'.format(kernel))
     if kernel == 'gemm' and layer.packed is None:
         raise _lib.L3CError('convolution outside every MFMA kernel\'s preconditions (Cin % 16 != 0)')
     d = ConvDesc()
@@ -185,7 +170,6 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     d.KS, d.stride, d.dilation = layer.KS, layer.stride, layer.dilation
     d.epilogue = ((_lib.EPI_RELU if relu else 0) | (_lib.EPI_RESIDUAL if residual is not None else 0) |
                   (_lib.EPI_PIXEL_SHUFFLE if pixel_shuffle else 0))
-    d.out_dims = ptr(dims, torch.int32) if dims is not None else None
     if kernel == 'wino2':
         _lib.call_xcheck('l3c_conv_wino', d, stream())
         return out
@@ -206,7 +190,7 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     return out
 
 
-def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True, dims=None):
+def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True):
     """5x5 stride 2 in polyphase form on the F(4x4,3x3) kernel: all four phases in one launch, or (fused=False) four phase launches
     accumulating into `out` (the first carries the bias)."""
     B, H, W, cstride = x.shape
@@ -221,7 +205,6 @@ def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True, dims=None):
         d.out, d.out_cstride, d.out_coff = ptr(out, torch.float32), out.shape[-1], out_coff
         d.B, d.Hin, d.Win, d.Cin, d.Cout = B, H, W, layer.Cin, layer.Cout
         d.KS, d.stride, d.dilation, d.epilogue = 5, 2, 1, 0
-        d.out_dims = ptr(dims, torch.int32) if dims is not None else None
         call('l3c_conv_wino4_stride2', d, stream())
     for k, (a, b) in enumerate(() if fused else ((0, 0), (0, 1), (1, 0), (1, 1))):
         d = ConvDesc()
@@ -234,7 +217,6 @@ def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True, dims=None):
         d.B, d.Hin, d.Win, d.Cin, d.Cout = B, H, W, layer.Cin, layer.Cout
         d.KS, d.stride, d.dilation = 3, 2, 1
         d.epilogue = _lib.EPI_RESIDUAL if k else 0
-        d.out_dims = ptr(dims, torch.int32) if dims is not None else None
         call('l3c_conv_wino4_phase', d, a, b, stream())
     if PROFILE is not None:
         e1.record()
@@ -243,15 +225,14 @@ def _conv_poly5(x, layer, out, in_coff, out_coff, fused=True, dims=None):
     return out
 
 
-def rgb_head(img, ms1_w, ms1_b, ms2_w, ms2_b, conv_w, conv_b, want_shifted=False, canvas=None):
+def rgb_head(img, ms1_w, ms1_b, ms2_w, ms2_b, conv_w, conv_b, want_shifted=False):
     """img (B,3,H,W) planar 0..255 -> (B,H,W,Cf) pixel-major features [, (B,3,H,W) mean-shifted image]."""
     B, _, H, W = img.shape
     Cf = conv_w.shape[0]
-    out = (torch.zeros if canvas is not None else torch.empty)(B, H, W, Cf, dtype=torch.float32, device=img.device)
+    out = torch.empty(B, H, W, Cf, dtype=torch.float32, device=img.device)
     shifted = torch.empty_like(img) if want_shifted else None
-    dims = canvas.table(H) if canvas is not None else None
     call('l3c_rgb_head', ptr(img, torch.float32), ptr(ms1_w), ptr(ms1_b), ptr(ms2_w), ptr(ms2_b), ptr(conv_w),
-         ptr(conv_b), B, H, W, Cf, ptr(out), ptr(shifted), ptr(dims, torch.int32) if dims is not None else None, stream())
+         ptr(conv_b), B, H, W, Cf, ptr(out), ptr(shifted), stream())
     return (out, shifted) if want_shifted else out
 
 
@@ -267,14 +248,13 @@ def to_q_quantize(feat, w, b, levels, want_bn=False):
     return (sym, bn_q, bn) if want_bn else (sym, bn_q)
 
 
-def dec_head(bn_q, w, b, fuse=None, canvas=None):
+def dec_head(bn_q, w, b, fuse=None):
     """bn_q (B,C,H,W) planar -> (B,H,W,Cf) pixel-major, + fuse."""
     B, C, H, W = bn_q.shape
     Cf = w.shape[0]
-    out = (torch.zeros if canvas is not None else torch.empty)(B, H, W, Cf, dtype=torch.float32, device=bn_q.device)
-    dims = canvas.table(H) if canvas is not None else None
+    out = torch.empty(B, H, W, Cf, dtype=torch.float32, device=bn_q.device)
     call('l3c_dec_head', ptr(bn_q, torch.float32), ptr(w), ptr(b), ptr(fuse, torch.float32) if fuse is not None else None,
-         B, H * W, C, Cf, ptr(out), ptr(dims, torch.int32) if dims is not None else None, W, stream())
+         B, H * W, C, Cf, ptr(out), stream())
     return out
 
 

@@ -240,12 +240,12 @@ class MultiscaleTester(object):
         self.test_output_cache[test_id] = result
         return result
 
-    def _iter_images(self, ps):
-        """(index, path, uint8 CHW tensor) in order; the files are read and decoded by `io_threads` worker threads a few images
-        ahead of the consumer (PIL releases the GIL while it inflates a PNG: reference images_loader.py:91-129 decodes on the
-        main thread, one image at a time)."""
+    def _iter_images(self, ps, ahead=None):
+        """(index, path, uint8 CHW tensor) in order; the files are read and decoded by `io_threads` worker threads `ahead` images
+        (default: two per thread) ahead of the consumer (PIL releases the GIL while it inflates a PNG: reference
+        images_loader.py:91-129 decodes on the main thread, one image at a time)."""
         import concurrent.futures
-        ahead = 2 * self.io_threads
+        ahead = max(2 * self.io_threads, ahead or 0)
         with concurrent.futures.ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix='l3c-read') as pool:
             futs = collections.deque()
             it = iter(enumerate(ps))
@@ -367,19 +367,94 @@ class MultiscaleTester(object):
     # ---- --write_to_files: real files, real round trip ---------------------------------------------------------------------
 
     def _test_write(self, testset):
+        """--write_to_files: every image -> a real `.l3c` file -> read back -> decoded -> compared with the input (reference :353-381,
+        one image at a time: encode, decode, assert_equal :373).  Here the images stream through in WINDOWS of `--write_window` images
+        (default 8 x --batch): a window is coded as a set (dataset_codec.encode_set: images of equal padded shape share a forward pass,
+        one grouped coder launch), its files are written by worker threads, read back from disk and decoded as a set (decode_set); the
+        reader threads decode the next window's image files meanwhile.  Images that need auto-crops (`.partN` files) and a window of 1
+        take the reference's one-image path.  The time report (`--time_report`) names every stage, per window."""
+        from ..helpers import dataset_codec
         test_result = TestResult('bpsp')
         out_dir = self.flags.write_to_files
         os.makedirs(out_dir, exist_ok=True)
-        for i, img_p, raw in self._iter_images(testset.ps):       # the next images are decoded while this one is on the GPU
+        window = int(getattr(self.flags, 'write_window', None) or 8 * self.max_batch)
+        buf, state = [], {'windows': 0}
+
+        def flush():
+            if not buf:
+                return
+            with self.times.skip(state['windows'] == 0):            # the first window is the warm-up (reference: the first image, :297)
+                self._write_window(buf, out_dir, test_result, dataset_codec)
+            state['windows'] += 1
+            del buf[:]
+
+        t_read = time.time()
+        for i, img_p, raw in self._iter_images(testset.ps, ahead=window):   # the NEXT window's files are read and decoded while this one is on the GPU
             filename = os.path.splitext(os.path.basename(img_p))[0]
-            print('***', filename)
-            img = raw.unsqueeze(0).long()
-            with self.times.skip(i == 0):
-                test_result[filename] = self._write_to_file(img, os.path.join(out_dir, filename + _FILE_EXT))
-            print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+            if window <= 1 or auto_crop.needs_crop(raw.unsqueeze(0)):
+                flush()
+                print('***', filename)
+                img = raw.unsqueeze(0).long()
+                with self.times.skip(i == 0):
+                    test_result[filename] = self._write_to_file(img, os.path.join(out_dir, filename + _FILE_EXT))
+                print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+                continue
+            buf.append((i, filename, raw))
+            if len(buf) >= window:
+                self._note('=== wait for the image readers (file read + PNG decode on {} threads, a window ahead of the GPU)'.format(
+                    self.io_threads), time.time() - t_read, state['windows'] == 0)
+                flush()
+                t_read = time.time()
+        flush()
         if self.file_writer is not None:
             self.file_writer.wait()
+        if getattr(self.flags, 'time_report', None):
+            with open(self.flags.time_report, 'w') as f:
+                f.write('Average times:\n')
+                f.write('\n'.join(self.times.get_mean_strs()))
         return test_result
+
+    def _note(self, name, seconds, skip):
+        self.times.last[name] = seconds
+        if not skip:
+            self.times.times.setdefault(name, []).append(seconds)
+
+    def _write_window(self, buf, out_dir, test_result, dataset_codec):
+        order = [i for i, _, _ in buf]
+        imgs = {i: raw.contiguous() for i, _, raw in buf}
+        names = {i: fn for i, fn, _ in buf}
+        paths_ = {i: os.path.join(out_dir, names[i] + _FILE_EXT) for i in order}
+        fac = self._padding_fac()
+        for i in order:
+            for stale in (paths_[i], paths_[i] + part_suffix_helper.make_part_suffix(0)):
+                if os.path.isfile(stale):
+                    os.remove(stale)
+        with self.times.run('=== bc.encode, {} images as a set (H2D, forward, heads, coder, file assembly, D2H)'.format(len(order))):
+            files, _, _ = dataset_codec.encode_set(self.bc, imgs, order, max_batch=self.max_batch, fac=fac)
+        with self.times.run('=== file write ({} files, worker threads, waited for)'.format(len(order))):
+            for i in order:
+                self.bc._write_file(paths_[i], files[i])
+            if self.file_writer is not None:
+                self.file_writer.wait()
+        if getattr(self.flags, 'round_trip', True) is False:      # (bench.py --config files: the encode half alone, PNG files -> .l3c files)
+            for i in order:
+                _, H, W = imgs[i].shape
+                test_result[names[i]] = len(files[i]) * 8 / float(3 * (-(-H // fac) * fac) * (-(-W // fac) * fac))
+            return
+        with self.times.run('=== file read ({} files)'.format(len(order))):
+            datas = {i: self.bc._read_file(paths_[i]) for i in order}
+        with self.times.run('=== bc.decode, {} files as a set (parse, H2D, decode, D2H)'.format(len(order))):
+            back = dataset_codec.decode_set(self.bc, datas, order, max_batch=self.max_batch)
+        with self.times.run('=== compare with the inputs'):
+            for i in order:
+                if not torch.equal(back[i], imgs[i]):
+                    raise AssertionError('decoded image differs from the input: {}'.format(paths_[i]))
+        for i in order:
+            _, H, W = imgs[i].shape
+            Hp, Wp = -(-H // fac) * fac, -(-W // fac) * fac
+            test_result[names[i]] = len(datas[i]) * 8 / float(3 * Hp * Wp)      # as the reference: over the PADDED sub-pixels (bitcoding.py:108-110)
+            print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, names[i], i, test_result.metric_name, test_result.mean()))
+        print('\n'.join(self.times.get_last_strs()))
 
     def _write_to_file(self, img, out_p):
         for stale in [out_p] + ([p for p in part_suffix_helper.iter_part_suffixes(out_p + '.part0')]
