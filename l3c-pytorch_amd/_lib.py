@@ -132,7 +132,7 @@ XCHECK_PROTOTYPES = {
     'l3c_conv_wino4w_pack_weights': (c_int, [c_vp, c_int, c_int, c_vp, c_vp]),
     'l3c_conv_wino4w': (c_int, [ctypes.POINTER(ConvDesc), c_int, c_vp]),
 }
-XCHECK_LIB_PATH = os.path.join(_HERE, 'csrc', 'libl3c_hip_xcheck.so')
+XCHECK_LIB_PATH = os.environ.get('L3C_XCHECK_LIB') or os.path.join(_HERE, 'csrc', 'libl3c_hip_xcheck.so')   # (L3C_XCHECK_LIB: a development variant)
 
 _lib = None
 _xcheck = None

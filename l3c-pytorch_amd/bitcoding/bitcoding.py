@@ -504,7 +504,7 @@ class Bitcoding(object):
                 bn_prev = bn_prev - _rgb_mean_tensor(bn_prev.device)
         return sym.to(out_dtype), parsed.padding
 
-    N_DECODE_LANES = 2
+    N_DECODE_LANES = 8       # decode_many: lanes when every batch is small (fewer than 64 images: latency-bound chains); large batches run one after the other
 
     def _lanes(self, n, chain_cus):
         """`n` pairs (main stream, side stream) for decode_many.  chain_cus > 0: every side stream -- the latency-bound range-decoder
@@ -535,7 +535,13 @@ class Bitcoding(object):
         of entry i, which leave most of the machine idle (3 B wavefronts).  Within one entry the two cannot overlap: the chains need the
         tables, the tables need P.  One host thread enqueues everything (an entry costs a few milliseconds of host time since the RGB
         schedule is one library call); a lane's previous entry is waited for before its buffers are reused."""
+        # [measured, profiles/r06_decode_lanes_probe.log] batches of 128: two lanes 62-146 MPix/s (erratic: the lanes' long decoder launches
+        # and convolutions alias on the hardware queues) against 142-144 for one lane; with the chains on 64 CUs of their own 125-147 --
+        # the round-5 verdict's bar for keeping the overlap was 180: NOT kept for large batches.  Small batches are latency-bound (one image:
+        # 93 ms whatever the machine does) and scale with the lanes.
         n = self.N_DECODE_LANES if lanes is None else int(lanes)
+        if lanes is None and max(len(f) for f in batches) >= 64:
+            n = 1
         result = [None] * len(batches)
         if n <= 1 or len(batches) <= 1:
             for i, files in enumerate(batches):
@@ -824,7 +830,8 @@ class _H2DRing(object):
         self.events[k].record(torch.cuda.current_stream())
 
 
-_UPLOAD_RING = _H2DRing()
+_UPLOAD_RING = _H2DRing(6)
+_UPLOAD_STREAM = [None]      # the files of a batch cross PCIe on a stream of their own: a lane's upload never queues behind that lane's previous batch
 
 
 class _DeviceStreams(object):
@@ -871,8 +878,16 @@ def _upload_streams(files, parsed):
     st[table_at:table_at + 8 * S] = src.view(np.uint8)
     st[table_at + 8 * S:table_at + 16 * S] = dst.view(np.uint8)
     st[table_at + 16 * S:table_at + 20 * S] = lens.astype(np.int32).view(np.uint8)
-    dev = stage.cuda(non_blocking=True)
-    _UPLOAD_RING.sent(k)
+    if _UPLOAD_STREAM[0] is None:
+        _UPLOAD_STREAM[0] = torch.cuda.Stream()
+    cur = torch.cuda.current_stream()
+    with torch.cuda.stream(_UPLOAD_STREAM[0]):
+        dev = stage.cuda(non_blocking=True)
+        _UPLOAD_RING.sent(k)
+        copied = torch.cuda.Event()
+        copied.record(_UPLOAD_STREAM[0])
+    cur.wait_event(copied)
+    dev.record_stream(cur)
     src_d = dev[table_at:table_at + 8 * S].view(torch.int64)
     dst_d = dev[table_at + 8 * S:table_at + 16 * S].view(torch.int64)
     len_d = dev[table_at + 16 * S:table_at + 20 * S].view(torch.int32)

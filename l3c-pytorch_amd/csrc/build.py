@@ -76,4 +76,7 @@ if __name__ == '__main__':
         n = sys.argv[sys.argv.index('--variant') + 1]
         flags = sys.argv[sys.argv.index('--variant') + 2].split()
         kw.update(extra=flags, lib=os.path.join(HERE, 'libl3c_hip_{}.so'.format(n)), objdir='_obj_l3c_' + n)
+        if '--xcheck' in sys.argv:       # ... of the TEST-ONLY library instead (loaded through L3C_XCHECK_LIB): the probe kernels live there
+            print(_build(XCHECK_SOURCES, kw['force'], kw['verbose'], flags, os.path.join(HERE, 'libl3c_hip_xcheck_{}.so'.format(n)), '_obj_l3c_x' + n))
+            sys.exit(0)
     print(build(**kw))

@@ -60,6 +60,19 @@ constexpr int ROW_SLOTS = 2 * PWD;              // 16-byte pieces of a patch row
 constexpr int NIT = 3;                          // pieces per fetching thread: rows r0, r0 + 6, r0 + 12
 constexpr int BR = 6;                           // depth of the weight ring (positions ahead); a chunk has 9: slot (q + 3 par) % 6
 constexpr int AR = 3;                           // depth of the A ring
+// Development probes (csrc/build.py --variant NAME "-DL3C_W4W_PROBE=N"; WRONG results, only the time means something): bit 0 no output
+// transform / exchange (one store per tile keeps the accumulators alive), 1 the exchange and the transform without the global stores, 2 no input
+// transform inside the chunk loop, 3 no MFMA (one v_add in its place), 4 no patch fetch, 5 no weight loads inside the loop
+#ifndef L3C_W4W_PROBE
+#define L3C_W4W_PROBE 0
+#endif
+// Output transform: 0 = first version (four rounds of 8 tiles through one 73 728-byte buffer, two barriers a round), 1 = eight half rounds through
+// two buffers, the next half round's writes issued before this one's reads (one barrier a half round).  [measured, 64 -> 64 at 256x384x32, tiles
+// per block 6 / 12: version 0 0.747 / 0.734 ms, version 1 0.766 / 0.755 ms (profiles/r06_wino4w_probe.log): the pipelined form reads more (30 values
+// per thread and half round instead of 36 per round) and wins nothing back -- left at 0]
+#ifndef L3C_W4W_EPI
+#define L3C_W4W_EPI 0
+#endif
 
 // one 6-vector through A^T (output transform), four outputs -- as conv_wino4.hip
 __device__ __forceinline__ void at6(float m0, float m1, float m2, float m3, float m4, float m5, float (&y)[4]) {
@@ -116,8 +129,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
     f32x4 stage[NIT];
     auto fetch_patch = [&]() {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it)
-            stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off + it * pf_row_b, pf_cc * CK * 4, 0));
+        for (int it = 0; it < NIT; ++it) {
+            if constexpr (L3C_W4W_PROBE & 16) stage[it] = f32x4{1.f, 2.f, 3.f, 4.f};
+            else stage[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rsrc, patch_off + it * pf_row_b, pf_cc * CK * 4, 0));
+        }
         pf_advance();
     };
     auto store_patch = [&](float *dst) {
@@ -224,7 +239,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
         // at the start.  LAST (last chunk of a tile): no transform (the epilogue's exchange uses both V buffers; the next tile's first
         // transform follows the epilogue).
         auto chunk = [&](const int cc, auto last_c, auto par_c, auto first_c) __attribute__((always_inline)) {
-            constexpr bool LAST = decltype(last_c)::value, FIRST = decltype(first_c)::value;
+            constexpr bool LASTC = decltype(last_c)::value, FIRST = decltype(first_c)::value;
+            constexpr bool LAST = LASTC || (L3C_W4W_PROBE & 4);   // (probe bit 2: no transform in any chunk)
             constexpr int par = decltype(par_c)::value;
             const int cc_b = cc + 1 == n_cc ? 0 : cc + 1;
             const float *a_cur = lds + (par ? V_OFF1 : V_OFF0) + a_lane;
@@ -238,7 +254,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
             }
 #define L3C_W4W_MFMA(Q, S)                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                   \
-    acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S], Bv[S], acc[Q], 0, 0, 0);                        \
+    if constexpr (L3C_W4W_PROBE & 8) { asm volatile("v_add_f32 %0, %1, %2" : "+v"(acc[Q][0]) : "v"(A[S]), "v"(Bv[S])); } \
+    else acc[Q] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[S], Bv[S], acc[Q], 0, 0, 0);                   \
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
                 if (q == 8) {
                     // everything chunk g + 1 needs from this wavefront is issued: V[par ^ 1] written, patch g + 2 stored
                     __syncthreads();
-                    if constexpr (!LAST) {
+                    if constexpr (!LASTC) {
 #pragma unroll
                         for (int j = 0; j + 1 < AR; ++j) a_ring[j] = *reinterpret_cast<const f32x4 *>(a_nxt + j * VP);
                     }
@@ -264,8 +281,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
                 if (!LAST && q == 7) tr_row(v_next, 2);
                 // the rings are reloaded behind the position's last MFMA
                 if (q + AR < 9) a_ring[q % AR] = *reinterpret_cast<const f32x4 *>(a_cur + (q + AR) * VP);
-                if (!LAST && q == 8) a_ring[AR - 1] = *reinterpret_cast<const f32x4 *>(a_nxt + (AR - 1) * VP);
-                {
+                if (!LASTC && q == 8) a_ring[AR - 1] = *reinterpret_cast<const f32x4 *>(a_nxt + (AR - 1) * VP);
+                if constexpr (!(L3C_W4W_PROBE & 32)) {
                     const int nxt = q + BR;
                     b_ring[(q + 3 * par) % BR] = nxt < 9 ? fetch_b(cc, nxt) : fetch_b(cc_b, nxt - 9);
                 }
@@ -298,8 +315,85 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
             // issued its last read of V before any other one can pass that barrier and reach the writes below)
 
             // ---- output transform: four rounds, one per tile row.  X[position][tile of the row][channel] over V[0] | V[1].
-            float *X = lds + V_OFF0;
+            [[maybe_unused]] float *X = lds + V_OFF0;
             const int sx0 = (tx_first + t) * OW;
+            if constexpr (L3C_W4W_PROBE & 1) {
+                f32x16 sum = acc[0];
+#pragma unroll
+                for (int q = 1; q < 9; ++q) sum = sum + acc[q];
+                float v = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v += sum[r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, (sx0 * p.out_cstride + lane + 64 * wave) * 4, 0, 0);
+                __syncthreads();
+                if (t + 1 < n_t) {
+                    transform_all(lds + RAW_OFF0, lds + V_OFF0);
+                    __syncthreads();
+                }
+                continue;
+            }
+#if L3C_W4W_EPI == 1
+            // PIPELINED (second version): eight HALF rounds k = (tile row i = k >> 1, column pair jh = k & 1) of four tiles -- registers 4 i + 2 jh + jj,
+            // jj = 0, 1, i.e. tile columns 4 (lane >> 5) + 2 jh + jj -- through TWO 36 864-byte buffers (V[0], V[1]): the accumulators of half round
+            // k + 1 are written while half round k is read and transformed, one barrier per half round.  Readers: thread (tile slot ts = pg,
+            // row half = TH, channel = lane) computes output rows 2 TH, 2 TH + 1 of its tile from rows xi = TH .. TH + 4 of the transformed tile
+            // (A^T has a zero in column 5 of rows 0..2 and in column 0 of rows 1..3): 30 reads, the same arithmetic as at6.
+            {
+                auto write_half = [&](auto k_c) __attribute__((always_inline)) {
+                    constexpr int k = decltype(k_c)::value, i = k >> 1, jh = k & 1;
+                    float *x_dst = lds + ((k & 1) ? V_OFF1 : V_OFF0) + (9 * pg * 4 + 2 * (lane >> 5)) * 64 + h * 32 + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) x_dst[(q * 4 + jj) * 64] = acc[q][4 * i + 2 * jh + jj];
+                };
+                auto read_half = [&](auto k_c) __attribute__((always_inline)) {
+                    constexpr int k = decltype(k_c)::value, i = k >> 1, jh = k & 1;
+                    const float *x_src = lds + ((k & 1) ? V_OFF1 : V_OFF0) + pg * 64 + lane;     // tile slot pg = 2 (writer's lane half) + jj
+                    float tr[2][6];
+#pragma unroll
+                    for (int nu = 0; nu < 6; ++nu) {
+                        const float m1 = x_src[(1 * 6 + nu) * 256], m2 = x_src[(2 * 6 + nu) * 256], m3 = x_src[(3 * 6 + nu) * 256], m4 = x_src[(4 * 6 + nu) * 256];
+                        const float s1 = m1 + m2, d1 = m1 - m2;
+                        if constexpr (TH == 0) {
+                            const float m0 = x_src[(0 * 6 + nu) * 256];
+                            tr[0][nu] = (m0 + s1) + (m3 + m4);
+                            tr[1][nu] = d1 + __builtin_fmaf(-2.0f, m4, 0.5f * m3);
+                        } else {
+                            const float m5 = x_src[(5 * 6 + nu) * 256];
+                            tr[0][nu] = s1 + __builtin_fmaf(4.0f, m4, 0.25f * m3);
+                            tr[1][nu] = (d1 + __builtin_fmaf(-8.0f, m4, 0.125f * m3)) + m5;
+                        }
+                    }
+                    const int oy0 = sy0 + 4 * i + 2 * TH, ox0 = sx0 + 4 * (4 * (pg >> 1) + 2 * jh + (pg & 1));
+#pragma unroll
+                    for (int r = 0; r < 2; ++r) {
+                        float y[4];
+                        at6(tr[r][0], tr[r][1], tr[r][2], tr[r][3], tr[r][4], tr[r][5], y);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float v = y[j];
+                            if (p.relu) v = fmaxf(v, 0.0f);
+                            const bool ok = lane < p.Cout && oy0 + r < p.H && ox0 + j < p.W;
+                            const int off = ok ? (((4 * i + 2 * TH + r) * p.W + ox0 + j) * p.out_cstride + lane) * 4 : OOB;
+                            if constexpr (L3C_W4W_PROBE & 2) {
+                                if (v == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, 0, 0);
+                            } else
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, 0, 0);
+                        }
+                    }
+                };
+                write_half(std::integral_constant<int, 0>{});
+                __syncthreads();
+#define L3C_W4W_HALF(K)                                                               \
+    if constexpr (K < 7) write_half(std::integral_constant<int, (K < 7 ? K + 1 : 7)>{}); \
+    asm volatile("" ::: "memory");                                                    \
+    read_half(std::integral_constant<int, K>{});                                      \
+    __syncthreads();
+                L3C_W4W_HALF(0) L3C_W4W_HALF(1) L3C_W4W_HALF(2) L3C_W4W_HALF(3) L3C_W4W_HALF(4) L3C_W4W_HALF(5) L3C_W4W_HALF(6) L3C_W4W_HALF(7)
+#undef L3C_W4W_HALF
+            }
+#else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 // this wavefront's accumulators of tile row i: register 4 i + j = tile (row i, column 4 (lane >> 5) + j), channel 32 h + lane % 32
@@ -331,11 +425,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino4w_kernel(const W4wParams p) 
                         if (p.relu) v = fmaxf(v, 0.0f);
                         const bool ok = lane < p.Cout && oy0 + r < p.H && ox0 + j < p.W;
                         const int off = ok ? (((4 * i + r) * p.W + ox0 + j) * p.out_cstride + lane) * 4 : OOB;
+                        if constexpr (L3C_W4W_PROBE & 2) {
+                            if (v == 123.456f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, 0, 0);
+                        } else
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, off, 0, 0);
                     }
                 }
                 __syncthreads();
             }
+#endif
             // ---- the next tile's first transform (its patch 0 sits in raw[0], patch 1 in raw[1], patch 2 is in flight)
             if (t + 1 < n_t) {
                 transform_all(lds + RAW_OFF0, lds + V_OFF0);

@@ -68,8 +68,11 @@ def plan_set(shapes, order, max_batch, fac):
     return chunks, padded, pads, len(groups)
 
 
-def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8):
-    """imgs: {index: uint8 (3,H,W) HOST tensor}; order: the indices to code.  -> ({index: `.l3c` bytes}, number of distinct
+def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, n_pinned=8, shapes=None, loader=None, pool=None):
+    """imgs: {index: uint8 (3,H,W) HOST tensor}; order: the indices to code.  LAZY form (files on disk, test.py --write_to_files): `shapes` =
+    {index: (H, W)} known up front (an image file's header), `loader(index)` -> the tensor, run on the worker threads of `pool` in the
+    order the passes will be enqueued, so that reading and decoding the image files overlaps the GPU's work on the earlier passes; `imgs`
+    (may start empty) is filled with what was loaded.  -> ({index: `.l3c` bytes}, number of distinct
     padded shapes, number of forward passes).  `marks` (dict) receives host time stamps of the stages.  n_pinned: page-locked staging
     buffers of this process (helpers/sharding.host_budget: fewer per rank when several ranks share a host).
 
@@ -93,12 +96,19 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
         if marks is not None:
             marks[name] = time.perf_counter()
 
-    for i in order:   # the staging memcpy reinterprets the image's bytes: anything but host uint8 CHW would be silently cast / wrapped
-        t = imgs[i]
+    def check(i, t):   # the staging memcpy reinterprets the image's bytes: anything but host uint8 CHW would be silently cast / wrapped
         if t.dtype != torch.uint8 or t.is_cuda or t.dim() != 3 or t.shape[0] != 3 or not t.is_contiguous():
             raise ValueError('encode_set: image {} must be a contiguous host uint8 (3,H,W) tensor, got {} {} on {}'.format(
                 i, t.dtype, tuple(t.shape), t.device))
-    shapes = {i: tuple(imgs[i].shape[-2:]) for i in order}
+        if shapes is not None and tuple(t.shape[-2:]) != tuple(shapes[i]):
+            raise ValueError('encode_set: image {} is {} but was announced as {}'.format(i, tuple(t.shape[-2:]), tuple(shapes[i])))
+        return t
+
+    if loader is None:
+        for i in order:
+            check(i, imgs[i])
+        shapes = {i: tuple(imgs[i].shape[-2:]) for i in order}
+    futures = {}
     # (Round 4 also built passes that hold images of DIFFERENT padded shapes -- "canvas" batches: byte-identical files in 3-6x fewer passes, but
     # no faster [measured, profiles/r04_canvas_passes.log: 200 images 117.5 vs 116.7 MPix/s, 500 images 122.6 vs 146.9]: with three forward
     # streams the GPU is already > 90 % busy on the small passes.  Removed in round 6; the code is in the history, DESIGN_HISTORY.md.)
@@ -112,6 +122,11 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
 
     def upload(ci):
         chunk, (Hp, Wp) = chunks[ci], padded[ci]
+        t0 = time.perf_counter()
+        for i in chunk:
+            if i in futures:
+                imgs[i] = check(i, futures.pop(i).result())
+        spent['wait for the image readers'] += time.perf_counter() - t0
         sizes = [imgs[i].numel() for i in chunk]
         t0 = time.perf_counter()
         k, stage = ring.take(sum(sizes))
@@ -157,6 +172,10 @@ def encode_set(bc, imgs, order, max_batch=16, fac=8, marks=None, n_groups=None, 
         spent['collect files (sizes, assembly, D2H, slicing)'] += time.perf_counter() - t0
 
     weights = [len(c) * p[0] * p[1] for c, p in zip(chunks, padded)]
+    if loader is not None:      # the readers work through the images in the order encode_many enqueues the passes (largest first)
+        for ci in sorted(range(len(chunks)), key=lambda c: -weights[c]):
+            for i in chunks[ci]:
+                futures[i] = pool.submit(loader, i)
     if n_groups is None:
         n_groups = max(2, min(8, int(round(len(chunks) / 13.0))))
     bc.encode_many(list(range(len(chunks))), upload=upload, on_group=on_group, n_groups=n_groups, weights=weights)
@@ -191,7 +210,7 @@ def plan_decode_set(files, order, max_batch):
     return chunks, padded
 
 
-def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus=0, n_pinned=4):
+def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus=0, n_pinned=None):
     """files: {index: `.l3c` bytes} (as `encode_set` returns them); order: the indices to decode.  -> {index: uint8 (3,H,W) HOST tensor},
     the padding undone.  The mirror of `encode_set` for the reference's folder evaluation, which decodes EVERY file it wrote and
     compares it with the input (multiscale_tester.py:353-381, assert_equal at :373): files of equal padded shape share a batch,
@@ -204,6 +223,9 @@ def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus
         if marks is not None:
             marks[name] = time.perf_counter()
 
+    n_lanes = bc.N_DECODE_LANES if lanes is None else int(lanes)
+    if n_pinned is None:
+        n_pinned = n_lanes + 2          # a lane's finished batch must never wait for a free D2H buffer
     chunks, padded = plan_decode_set(files, order, max_batch)
     by_size = sorted(range(len(chunks)), key=lambda k: -len(chunks[k]) * padded[k][0] * padded[k][1])
     mark('plan (host)')

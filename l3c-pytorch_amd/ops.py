@@ -186,7 +186,9 @@ def conv(x, layer, out=None, in_coff=0, out_coff=0, residual=None, res_coff=0, r
     if PROFILE_DETAIL:
         key += ' {}->{} {}x{}{}{}'.format(layer.Cin, layer.Cout, Ho, Wo, ' +res' if residual is not None else '', ' shuffle' if pixel_shuffle else '')
     nbytes = 4.0 * B * (H * W * layer.Cin + Ho * Wo * layer.Cout * (2 if residual is not None else 1))   # in + out (+ residual), once
-    PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1))
+    # (sixth field: the kernel's template arguments as rocprofv3 prints them -- bench.py joins the PMC table's per-variant bytes with these)
+    variant = '{},{},{},false'.format(*('true' if f else 'false' for f in (relu, residual is not None, pixel_shuffle))) if kernel == 'wino4' else ''
+    PROFILE.append((key, 2.0 * B * Ho * Wo * layer.Cout * layer.Cin * layer.KS * layer.KS, nbytes, e0, e1, variant))
     return out
 
 

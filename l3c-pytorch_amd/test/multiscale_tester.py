@@ -369,43 +369,39 @@ class MultiscaleTester(object):
     def _test_write(self, testset):
         """--write_to_files: every image -> a real `.l3c` file -> read back -> decoded -> compared with the input (reference :353-381,
         one image at a time: encode, decode, assert_equal :373).  Here the images stream through in WINDOWS of `--write_window` images
-        (default 8 x --batch): a window is coded as a set (dataset_codec.encode_set: images of equal padded shape share a forward pass,
-        one grouped coder launch), its files are written by worker threads, read back from disk and decoded as a set (decode_set); the
-        reader threads decode the next window's image files meanwhile.  Images that need auto-crops (`.partN` files) and a window of 1
-        take the reference's one-image path.  The time report (`--time_report`) names every stage, per window."""
+        (default 32 x --batch): a window is coded as a set (dataset_codec.encode_set: images of equal padded shape share a forward pass,
+        one grouped coder launch) -- planned from the image files' HEADERS, the pixels read and decoded by the reader threads in the order
+        the passes are enqueued, i.e. while the GPU works on the earlier passes --, its files are written by worker threads, read back
+        from disk and decoded as a set (decode_set).  Images that need auto-crops (`.partN` files) and a window of 1 take the
+        reference's one-image path.  The time report (`--time_report`) names every stage, per window."""
+        import concurrent.futures
         from ..helpers import dataset_codec
         test_result = TestResult('bpsp')
         out_dir = self.flags.write_to_files
         os.makedirs(out_dir, exist_ok=True)
-        window = int(getattr(self.flags, 'write_window', None) or 8 * self.max_batch)
-        buf, state = [], {'windows': 0}
-
-        def flush():
-            if not buf:
-                return
-            with self.times.skip(state['windows'] == 0):            # the first window is the warm-up (reference: the first image, :297)
-                self._write_window(buf, out_dir, test_result, dataset_codec)
-            state['windows'] += 1
-            del buf[:]
-
-        t_read = time.time()
-        for i, img_p, raw in self._iter_images(testset.ps, ahead=window):   # the NEXT window's files are read and decoded while this one is on the GPU
-            filename = os.path.splitext(os.path.basename(img_p))[0]
-            if window <= 1 or auto_crop.needs_crop(raw.unsqueeze(0)):
-                flush()
-                print('***', filename)
-                img = raw.unsqueeze(0).long()
-                with self.times.skip(i == 0):
-                    test_result[filename] = self._write_to_file(img, os.path.join(out_dir, filename + _FILE_EXT))
-                print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
-                continue
-            buf.append((i, filename, raw))
-            if len(buf) >= window:
-                self._note('=== wait for the image readers (file read + PNG decode on {} threads, a window ahead of the GPU)'.format(
-                    self.io_threads), time.time() - t_read, state['windows'] == 0)
-                flush()
-                t_read = time.time()
-        flush()
+        window = int(getattr(self.flags, 'write_window', None) or 32 * self.max_batch)
+        # the first window is the warm-up (reference: the first image, :297) -- when there is more than one
+        skip_first = bool(getattr(self.flags, 'skip_first_window', True)) and len(testset.ps) > window
+        if window <= 1:
+            for i, img_p, raw in self._iter_images(testset.ps):       # the next images are decoded while this one is on the GPU
+                self._write_one(i, img_p, raw, out_dir, test_result)
+        else:
+            with concurrent.futures.ThreadPoolExecutor(max_workers=self.io_threads, thread_name_prefix='l3c-read') as pool:
+                buf, n_windows = [], 0
+                for i, img_p in enumerate(testset.ps):
+                    shape = self._image_shape(img_p)
+                    if auto_crop.needs_crop(torch.empty((1, 3) + shape, dtype=torch.uint8, device='meta')):
+                        self._write_one(i, img_p, self._load_uint8(img_p), out_dir, test_result)
+                        continue
+                    buf.append((i, img_p, shape))
+                    if len(buf) >= window or i + 1 == len(testset.ps):
+                        with self.times.skip(skip_first and n_windows == 0):
+                            self._write_window(buf, out_dir, test_result, dataset_codec, pool)
+                        n_windows += 1
+                        buf = []
+                if buf:
+                    with self.times.skip(skip_first and n_windows == 0):
+                        self._write_window(buf, out_dir, test_result, dataset_codec, pool)
         if self.file_writer is not None:
             self.file_writer.wait()
         if getattr(self.flags, 'time_report', None):
@@ -414,31 +410,51 @@ class MultiscaleTester(object):
                 f.write('\n'.join(self.times.get_mean_strs()))
         return test_result
 
-    def _note(self, name, seconds, skip):
+    def _image_shape(self, img_p):
+        """(H, W) as `_load_uint8` will return it, from the file's header alone (PIL opens lazily: no pixel is decoded)."""
+        with Image.open(img_p) as img:
+            w, h = img.size
+        crop = getattr(self.flags, 'crop', None)
+        return (crop, crop) if crop else (h, w)
+
+    def _write_one(self, i, img_p, raw, out_dir, test_result):
+        filename = os.path.splitext(os.path.basename(img_p))[0]
+        print('***', filename)
+        img = raw.unsqueeze(0).long()
+        with self.times.skip(i == 0):
+            test_result[filename] = self._write_to_file(img, os.path.join(out_dir, filename + _FILE_EXT))
+        print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, filename, i, test_result.metric_name, test_result.mean()))
+
+    def _note(self, name, seconds):
         self.times.last[name] = seconds
-        if not skip:
+        if not self.times._skip:
             self.times.times.setdefault(name, []).append(seconds)
 
-    def _write_window(self, buf, out_dir, test_result, dataset_codec):
+    def _write_window(self, buf, out_dir, test_result, dataset_codec, pool):
         order = [i for i, _, _ in buf]
-        imgs = {i: raw.contiguous() for i, _, raw in buf}
-        names = {i: fn for i, fn, _ in buf}
+        shapes = {i: shape for i, _, shape in buf}
+        src = {i: img_p for i, img_p, _ in buf}
+        names = {i: os.path.splitext(os.path.basename(img_p))[0] for i, img_p, _ in buf}
         paths_ = {i: os.path.join(out_dir, names[i] + _FILE_EXT) for i in order}
         fac = self._padding_fac()
         for i in order:
             for stale in (paths_[i], paths_[i] + part_suffix_helper.make_part_suffix(0)):
                 if os.path.isfile(stale):
                     os.remove(stale)
-        with self.times.run('=== bc.encode, {} images as a set (H2D, forward, heads, coder, file assembly, D2H)'.format(len(order))):
-            files, _, _ = dataset_codec.encode_set(self.bc, imgs, order, max_batch=self.max_batch, fac=fac)
+        imgs, marks = {}, {}
+        with self.times.run('=== bc.encode, {} image files as a set (read + PNG decode on {} threads || H2D, forward, heads, coder, file assembly, D2H)'.format(
+                len(order), self.io_threads)):
+            files, _, _ = dataset_codec.encode_set(self.bc, imgs, order, max_batch=self.max_batch, fac=fac, shapes=shapes,
+                                                   loader=lambda i: self._load_uint8(src[i]).contiguous(), pool=pool, marks=marks)
+        self._note('    of which the host waited for the image readers', marks.get('host seconds', {}).get('wait for the image readers', 0.0))
         with self.times.run('=== file write ({} files, worker threads, waited for)'.format(len(order))):
             for i in order:
                 self.bc._write_file(paths_[i], files[i])
             if self.file_writer is not None:
                 self.file_writer.wait()
-        if getattr(self.flags, 'round_trip', True) is False:      # (bench.py --config files: the encode half alone, PNG files -> .l3c files)
+        if getattr(self.flags, 'round_trip', True) is False:      # (bench.py --config files: the encode half alone, image files -> .l3c files)
             for i in order:
-                _, H, W = imgs[i].shape
+                H, W = shapes[i]
                 test_result[names[i]] = len(files[i]) * 8 / float(3 * (-(-H // fac) * fac) * (-(-W // fac) * fac))
             return
         with self.times.run('=== file read ({} files)'.format(len(order))):
@@ -450,7 +466,7 @@ class MultiscaleTester(object):
                 if not torch.equal(back[i], imgs[i]):
                     raise AssertionError('decoded image differs from the input: {}'.format(paths_[i]))
         for i in order:
-            _, H, W = imgs[i].shape
+            H, W = shapes[i]
             Hp, Wp = -(-H // fac) * fac, -(-W // fac) * fac
             test_result[names[i]] = len(datas[i]) * 8 / float(3 * Hp * Wp)      # as the reference: over the PADDED sub-pixels (bitcoding.py:108-110)
             print('{}: {} ({: 10d}): mean {}={}'.format(self.log_date, names[i], i, test_result.metric_name, test_result.mean()))

@@ -51,7 +51,7 @@ def main(argv=None):
     p.add_argument('--batch', type=int, default=8, help='crops of equal padded shape evaluated per forward')
     p.add_argument('--io_threads', type=int, default=4, help='worker threads that read and decode the image files ahead of the GPU')
     p.add_argument('--write_window', type=int, default=None,
-                   help='--write_to_files: images coded / decoded as one set (default 8 x --batch; 1 = one image at a time like the reference)')
+                   help='--write_to_files: images coded / decoded as one set (default 32 x --batch; 1 = one image at a time like the reference)')
     flags = p.parse_args(argv)
 
     if flags.compare_theory and not flags.write_to_files:

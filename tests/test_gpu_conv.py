@@ -490,3 +490,41 @@ def test_conv5x5_stride2_polyphase_vs_implicit_gemm_and_fp64(B, H, W, Cout):
     ops.conv(xd, layer, out=wide, out_coff=4, impl='poly5')
     assert torch.equal(wide[..., 4:4 + Cout].cpu().permute(0, 3, 1, 2), got)
     assert bool(torch.isnan(wide[..., :4]).all()) and bool(torch.isnan(wide[..., 4 + Cout:]).all())
+
+
+@pytest.mark.parametrize('B,H,W,Cout,relu', [(2, 50, 70, 64, True), (1, 16, 32, 64, False), (3, 37, 129, 64, True), (2, 40, 200, 40, False),
+                                            (1, 1, 1, 64, True), (1, 17, 33, 64, False)])
+def test_winograd_f4_probe_on_the_32x32x2_mfma(B, H, W, Cout, relu):
+    """The PROBE kernel of round 6 (csrc/conv_wino4w.hip, test-only library; round-5 verdict, next 1): F(4x4,3x3) with a wavefront owning 9 of
+    the 36 positions for 32 tiles x 32 channels on v_mfma_f32_32x32x2_f32, M exchanged through LDS for the output transform.  It must compute
+    the convolution: against fp64 within the tolerance of the product's F(4x4) tests (1e-4 on unit-scale data; measured 1.4e-5 -- the same as
+    conv_wino4_kernel's), against the product kernel within 3e-5 (two fp32 evaluations of the same transforms with the channel sums in another
+    order), and independently of its tiles-per-block schedule bit for bit.  Its TIME against the product is profiles/r06_wino4w_probe.log."""
+    import os
+    from l3c_pytorch_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    w = torch.randn(Cout, 64, 3, 3, generator=g) / 24
+    bias = torch.randn(Cout, generator=g)
+    layer = ops.PackedConv(w, bias)
+    x = torch.randn(B, H, W, 64, generator=g).cuda()
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1)
+    if relu:
+        ref = ref.clamp_min(0)
+    outs = []
+    old = os.environ.get('L3C_W4W_TPB')
+    try:
+        for tpb in ('1', '2', '0'):
+            os.environ['L3C_W4W_TPB'] = tpb
+            out = torch.full((B, H, W, Cout), float('nan'), device='cuda')
+            ops.conv(x, layer, out=out, relu=relu, impl='wino4w')
+            outs.append(out)
+    finally:
+        if old is None:
+            os.environ.pop('L3C_W4W_TPB', None)
+        else:
+            os.environ['L3C_W4W_TPB'] = old
+    err = (outs[0].double().cpu() - ref).abs().max().item()
+    assert err < 1e-4, err
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    prod = ops.conv(x, layer, relu=relu, impl='wino4')
+    assert (outs[0] - prod).abs().max().item() < 3e-5

@@ -414,3 +414,57 @@ def test_committed_hip_bitstream_fixtures_are_intact():
         img = np.load(os.path.join(golden, img_file))['img']
         assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == meta['pixels_sha256']
     assert all(len(rec['forward_64x96'][k]['P']) == 3 and len(rec['forward_64x96'][k]['S']) == 4 for k in ('default', 'calibrated'))
+
+
+def test_container_framing_parser_and_set_decode_plan():
+    """`parse_containers` walks the `.l3c` framing by its length fields only (bitcoding.py:326-375 of the reference) and is what the decoder
+    uploads by: offsets and lengths of every payload, (C, H, W) per scale record, padding; files that disagree in shape or are broken raise
+    ValueError; `plan_decode_set` groups files by the padded shape their own headers announce."""
+    import struct
+    import pytest
+    from l3c_pytorch_amd.bitcoding.bitcoding import _MAGIC_VALUE_SEP, parse_containers
+    from l3c_pytorch_amd.helpers import dataset_codec
+
+    def make(shapes, pay, padding=(0, 0, 0, 0)):
+        out = [struct.pack('<4H', *padding)]
+        for (C, H, W), lens in zip(shapes, pay):
+            out.append(struct.pack('<BHH', C, H, W))
+            for n in lens:
+                out += [struct.pack('<I', n), bytes(range(256)) * (n // 256) + bytes(n % 256)]
+            out.append(_MAGIC_VALUE_SEP)
+        return b''.join(out)
+
+    sh = [(5, 4, 6), (5, 8, 12), (5, 16, 24), (3, 32, 48)]
+    a = make(sh, [[3, 0, 7, 1, 2], [10] * 5, [300, 2, 2, 2, 2], [1000, 999, 998]], (1, 2, 3, 4))
+    b = make(sh, [[1] * 5, [2] * 5, [3] * 5, [4, 5, 6]])
+    p = parse_containers([a, b])
+    assert p.padding == [(1, 2, 3, 4), (0, 0, 0, 0)] and p.scales == sh
+    assert p.nbytes[0].tolist() == [[3, 0, 7, 1, 2], [1] * 5] and p.nbytes[3].tolist() == [[1000, 999, 998], [4, 5, 6]]
+    for k in range(4):
+        for bi, f in enumerate((a, b)):
+            for c in range(sh[k][0]):
+                o, n = int(p.offset[k][bi, c]), int(p.nbytes[k][bi, c])
+                assert struct.unpack_from('<I', f, o - 4)[0] == n
+    assert f[int(p.offset[3][1, 2]) + 6:][:4] == _MAGIC_VALUE_SEP
+    with pytest.raises(ValueError):
+        parse_containers([a, make([(5, 4, 6), (5, 8, 12), (5, 16, 24), (3, 32, 40)], [[1] * 5, [2] * 5, [3] * 5, [4, 5, 6]])])
+    with pytest.raises(ValueError):
+        parse_containers([a[:-3]])
+    with pytest.raises(ValueError):
+        parse_containers([a, make(sh[1:], [[2] * 5, [3] * 5, [4, 5, 6]])])
+    assert dataset_codec.file_padded_shape(a) == (32, 48)
+    c = make([(5, 8, 6), (5, 16, 12), (5, 32, 24), (3, 64, 48)], [[1] * 5, [2] * 5, [3] * 5, [4, 5, 6]])
+    chunks, padded = dataset_codec.plan_decode_set({0: a, 1: c, 2: b, 3: a, 4: a}, [0, 1, 2, 3, 4], 3)
+    assert sorted(map(tuple, chunks)) == [(0, 2, 3), (1,), (4,)] and sorted(padded) == [(32, 48), (32, 48), (64, 48)]
+
+
+def test_balanced_cu_sets_hold_every_xcd_equally():
+    import collections
+    from l3c_pytorch_amd.helpers import runtime
+    first, rest = runtime.balanced_cu_sets(256, 64)
+    assert len(first) == 64 and len(rest) == 192 and not set(first) & set(rest)
+    for numbering in (lambda i: i % 8, lambda i: i // 32):
+        assert sorted(collections.Counter(map(numbering, first)).values()) == [8] * 8
+    import pytest
+    with pytest.raises(ValueError):
+        runtime.balanced_cu_sets(256, 40)

@@ -28,6 +28,8 @@ for rep in range(2):
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     print('decode_batch B={}: host returned after {:.3f} s, GPU done after {:.3f} s'.format(B, t1 - t0, t2 - t0))
+torch.cuda.synchronize()
+time.sleep(0.3)            # a gap in the kernel trace: tools/decode_timeline.py cuts the LAST decode out at gaps > 100 ms
 pr = cProfile.Profile()
 pr.enable()
 dec, _ = bc.decode_batch(files)
