@@ -247,7 +247,7 @@ def contract(args, ranks, value, elapsed, **extra):
 # ---- headline: batches of 768x512 ------------------------------------------------------------------------------------------------
 
 
-PMC_TABLE = os.path.join('profiles', 'r05_pmc_bench.json')
+PMC_TABLE = os.path.join('profiles', 'r06_pmc_bench.json')
 
 
 def load_json(rel):
@@ -290,7 +290,7 @@ ROOFLINE_KERNEL_SOURCES = ('conv_wino4.hip', 'conv_pw.hip', 'conv_mfma.hip', 'l3
 
 
 def load_pmc_table():
-    """profiles/r05_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
+    """profiles/r06_pmc_bench.json: per-launch HBM bytes (FETCH_SIZE, WRITE_SIZE passes) and SQ/GRBM counters of a rocprofv3
     --pmc run of THIS script, reduced by tools/pmc_bench.py and stamped with csrc_stamp() of the sources it was taken on.
     -> (table or None, 'current' | 'stale' | 'absent')."""
     try:
@@ -687,10 +687,11 @@ def run_dataset(args, ranks):
     # on the host -- and compared with its input, like the reference's folder evaluation does (multiscale_tester.py:353-381, assert_equal :373);
     # files of equal padded shape share a batch, the batches stream through Bitcoding.decode_many
     dec_seconds, lanes = [], int(os.environ.get('L3C_DECODE_LANES', '0')) or None
+    ragged = {'0': False, '1': True}.get(os.environ.get('L3C_DECODE_RAGGED'))      # (development: A/B of the grouped RGB decode; None = the product's choice)
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        back = dataset_codec.decode_set(bc, files, mine, max_batch=args.max_batch, lanes=lanes)
+        back = dataset_codec.decode_set(bc, files, mine, max_batch=args.max_batch, lanes=lanes, ragged=ragged)
         torch.cuda.synchronize()
         dec_seconds.append(time.perf_counter() - t0)
     wrong = [i for i in mine if not torch.equal(back[i], imgs[i])]
@@ -711,7 +712,7 @@ def run_dataset(args, ranks):
             bpsp=round(tot_bits / (3 * tot_px), 4), megapixels=round(tot_px / 1e6, 1),
             decode={'value': round(pixels / 1e6 / dec_best, 2), 'unit': 'MPix/s', 'images_decoded_on_rank0': len(mine), 'lossless': 'every image compared with its input',
                     'seconds_rank0': [round(t, 4) for t in dec_seconds], 'timing': 'best of the two passes after the first one of the process',
-                    'lanes': lanes or bc.N_DECODE_LANES,
+                    'lanes': lanes or bc.N_DECODE_LANES, 'ragged_rgb': True if ragged is None else ragged,
                     'note': 'host .l3c bytes -> host uint8 pixels of EVERY file the encode leg wrote (dataset_codec.decode_set): framing parsed on the host, '
                             'files uploaded as they are, batches of equal padded shape streamed through Bitcoding.decode_many'},
             per_step={'seconds_rank0': [round(t, 4) for t in step_seconds],

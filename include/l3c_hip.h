@@ -182,6 +182,14 @@ typedef struct {
     const float *targets;
     int64_t HW, pix0;
     int C, K, c;
+    /* RAGGED batches (round 6; all NULL / 0: the rectangular form above).  Streams of DIFFERENT lengths -- the images of a set decode have
+     * different sizes -- in one launch: stream s decodes r_npix[s] symbols from the rows at BYTE offset r_table_off[s] of `cdf` (its full-size
+     * slot of r_npix[s] * Lp entries) and writes them to sym_out + r_C * r_pixbase[s] + r_c * r_hw[s] + r_pix0[s], i.e. into channel r_c of an
+     * image whose r_C planes of r_hw[s] symbols start at element r_C * r_pixbase[s]; P / sym_all of the window fields are indexed the same way
+     * (image s: pixels r_pixbase[s] .. + r_hw[s]).  n_sym / sym_stride / sym_offset / HW / pix0 are ignored; r_table_bytes = size of the table. */
+    const int64_t *r_npix, *r_table_off, *r_pixbase, *r_hw, *r_pix0;   /* device, [n_streams] each */
+    int r_C, r_c;
+    int64_t r_table_bytes;
 } l3c_ac_decode_part;
 int64_t l3c_ac_decode_state_bytes(void);
 int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_stream_t stream);
@@ -221,6 +229,35 @@ typedef struct {
     void *workspace;
     int64_t workspace_bytes;
 } l3c_rgb_decode_desc;
+/*
+ * The same for a RAGGED batch (round 6): B images of DIFFERENT sizes decoded in lock step -- one grouped table launch and one decoder
+ * launch per pipeline step for all of them -- so that a set of differently sized images (the reference's folder evaluation,
+ * test/multiscale_tester.py:353-381) is not decoded one latency-bound image after the other.  Every image has the same NUMBER of chunks;
+ * image b's chunk j is pixels [chunk_pix0_host[j * B + b], + chunk_npix_host[j * B + b]).  P / sym ragged as for
+ * l3c_dmll_cdf_table_ragged with pixbase[b] = sum of hw_host[0 .. b).  `tables_dev`: device int64 array the CALLER has uploaded:
+ * pixbase [B] | hw [B] | pix0 [n_chunks][B] | npix [n_chunks][B] | table_off [n_chunks][B], table_off[j][b] = 514 * sum of npix[j][0 .. b).
+ */
+typedef struct {
+    const float *P;
+    const float *targets;
+    int16_t *sym;
+    int64_t B;
+    const int64_t *hw_host;
+    int K;
+    const uint8_t *in;
+    const int64_t *in_offsets;
+    const uint32_t *in_nbytes;
+    int n_chunks;
+    const int64_t *chunk_pix0_host;
+    const int64_t *chunk_npix_host;
+    const int64_t *tables_dev;
+    int lag;
+    int window_mode;
+    void *workspace;
+    int64_t workspace_bytes;
+} l3c_rgb_ragged_desc;
+int64_t l3c_decode_rgb_ragged_workspace_bytes(int64_t B, int64_t max_chunk_total_npix, int n_chunks, int lag);
+int l3c_decode_rgb_ragged(const l3c_rgb_ragged_desc *desc_host, l3c_stream_t main_stream, l3c_stream_t side_stream);
 int64_t l3c_decode_rgb_workspace_bytes(int64_t B, int64_t max_chunk_npix, int n_chunks, int lag);
 /* byte offset, inside the workspace, of the window statistics int32 [3][n_chunks + 2][B] (slot j + 2 = what chunk j's decoders reported; tests) */
 int64_t l3c_decode_rgb_stats_offset(int64_t B, int64_t max_chunk_npix, int n_chunks, int lag);
@@ -276,6 +313,25 @@ typedef struct {
 } l3c_table_part;
 int l3c_dmll_cdf_table_parts(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
                              int Lp, const l3c_table_part *parts_host, int n_parts, l3c_stream_t stream);
+/*
+ * RAGGED form (round 6): the images of the batch have DIFFERENT sizes -- P is [sum_b HW_b][Kp] with image b's pixels from pixel pixbase[b]
+ * on, sym holds image b's C planes of HW_b symbols from element C * pixbase[b] on -- and every part gives, per image, its own pixel
+ * range and the byte offset of its rows in the part's table.  parts_host[i].pix0 is ignored, .npix = the LONGEST range of the part.
+ */
+typedef struct {
+    int64_t B;                 /* images */
+    int64_t max_hw;            /* the largest HW_b */
+    const int64_t *pixbase;    /* device [B] */
+    const int64_t *hw;         /* device [B] */
+} l3c_ragged_batch;
+typedef struct {
+    const int64_t *pix0;       /* device [B]: first pixel of image b's range of this part */
+    const int64_t *npix;       /* device [B]: its length (0: nothing for this image) */
+    const int64_t *table_off;  /* device [B]: BYTE offset of image b's rows inside the part's table */
+} l3c_ragged_part;
+int l3c_dmll_cdf_table_ragged(const float *P, const int16_t *sym, const float *targets, const l3c_ragged_batch *batch_host, int C, int K,
+                              int rgb, int Lp, const l3c_table_part *parts_host, const l3c_ragged_part *ragged_parts_host, int n_parts,
+                              l3c_stream_t stream);
 
 /*
  * Fused encoder head: straight from the network output P and the symbols to the packed coding intervals of every

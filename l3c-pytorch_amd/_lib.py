@@ -47,7 +47,9 @@ class AcDecodePart(ctypes.Structure):
                 ('n_streams', c_i64), ('n_sym', c_i64), ('not_monotone_flag', c_vp), ('state_in', c_vp),
                 ('state_out', c_vp), ('final_chunk', c_int), ('sym_out', c_vp), ('sym_stride', c_i64), ('sym_offset', c_i64),
                 ('window_stats_in', c_vp), ('window_stats_out', c_vp), ('P', c_vp), ('sym_all', c_vp), ('targets', c_vp),
-                ('HW', c_i64), ('pix0', c_i64), ('C', c_int), ('K', c_int), ('c', c_int)]
+                ('HW', c_i64), ('pix0', c_i64), ('C', c_int), ('K', c_int), ('c', c_int),
+                ('r_npix', c_vp), ('r_table_off', c_vp), ('r_pixbase', c_vp), ('r_hw', c_vp), ('r_pix0', c_vp),
+                ('r_C', c_int), ('r_c', c_int), ('r_table_bytes', c_i64)]
 
 
 class TablePart(ctypes.Structure):
@@ -60,6 +62,24 @@ class RgbDecodeDesc(ctypes.Structure):
     _fields_ = [('P', c_vp), ('targets', c_vp), ('sym', c_vp), ('B', c_i64), ('HW', c_i64), ('K', c_int),
                 ('in_', c_vp), ('in_offsets', c_vp), ('in_nbytes', c_vp), ('n_chunks', c_int),
                 ('chunk_pix0_host', ctypes.POINTER(c_i64)), ('chunk_npix_host', ctypes.POINTER(c_i64)),
+                ('lag', c_int), ('window_mode', c_int), ('workspace', c_vp), ('workspace_bytes', c_i64)]
+
+
+class RaggedBatch(ctypes.Structure):
+    """l3c_ragged_batch (include/l3c_hip.h)."""
+    _fields_ = [('B', c_i64), ('max_hw', c_i64), ('pixbase', c_vp), ('hw', c_vp)]
+
+
+class RaggedPart(ctypes.Structure):
+    """l3c_ragged_part (include/l3c_hip.h)."""
+    _fields_ = [('pix0', c_vp), ('npix', c_vp), ('table_off', c_vp)]
+
+
+class RgbRaggedDesc(ctypes.Structure):
+    """l3c_rgb_ragged_desc (include/l3c_hip.h)."""
+    _fields_ = [('P', c_vp), ('targets', c_vp), ('sym', c_vp), ('B', c_i64), ('hw_host', ctypes.POINTER(c_i64)), ('K', c_int),
+                ('in_', c_vp), ('in_offsets', c_vp), ('in_nbytes', c_vp), ('n_chunks', c_int),
+                ('chunk_pix0_host', ctypes.POINTER(c_i64)), ('chunk_npix_host', ctypes.POINTER(c_i64)), ('tables_dev', c_vp),
                 ('lag', c_int), ('window_mode', c_int), ('workspace', c_vp), ('workspace_bytes', c_i64)]
 
 
@@ -88,6 +108,10 @@ PROTOTYPES = {
     'l3c_decode_rgb_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_int]),
     'l3c_decode_rgb_stats_offset': (c_i64, [c_i64, c_i64, c_int, c_int]),
     'l3c_decode_rgb': (c_int, [ctypes.POINTER(RgbDecodeDesc), c_vp, c_vp]),
+    'l3c_decode_rgb_ragged_workspace_bytes': (c_i64, [c_i64, c_i64, c_int, c_int]),
+    'l3c_decode_rgb_ragged': (c_int, [ctypes.POINTER(RgbRaggedDesc), c_vp, c_vp]),
+    'l3c_dmll_cdf_table_ragged': (c_int, [c_vp, c_vp, c_vp, ctypes.POINTER(RaggedBatch), c_int, c_int, c_int, c_int, ctypes.POINTER(TablePart),
+                                          ctypes.POINTER(RaggedPart), c_int, c_vp]),
     'l3c_ac_decode_state_bytes': (c_i64, []),
     'l3c_ac_decode_chunks': (c_int, [ctypes.POINTER(AcDecodePart), c_int, c_vp]),
     'l3c_ac_decode': (c_int, [c_vp, c_i64, c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_vp]),

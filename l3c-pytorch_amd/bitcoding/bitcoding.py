@@ -448,10 +448,13 @@ class Bitcoding(object):
         with torch.cuda.stream(first.coder_stream):
             on_group([(k, result[k]) for k in indices])
 
-    def decode_batch(self, files, out_dtype=torch.int64):
+    def decode_batch(self, files, out_dtype=torch.int64, defer_rgb=None):
         """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU (the reference's
         dtype, bitcoding.py:125-161; out_dtype: torch.uint8 / int16 for callers that want the pixels without the 8-byte form),
         list of padding tuples).
+        defer_rgb (decode_many's grouped form): a callable (B, H, W, Kp) -> contiguous device tensor that P of the RGB scale is written
+        into; the call then stops BEFORE the RGB scale and returns a `_DeferredRGB` (the set decoder runs the RGB scales of many
+        batches of different shapes as ONE ragged batch).
         Round 6: the host only parses the FRAMING (a few length fields per file, `parse_containers`); the files cross PCIe as they
         are, in one copy from a page-locked buffer, and one kernel (l3c_container_read) cuts every stream out of them in the
         aligned, zero-padded form the range decoders read -- before, 14 `pack_streams` calls copied every payload on the host
@@ -492,6 +495,10 @@ class Bitcoding(object):
                     raise ValueError('invalid file: scale {} header (C, H, W) = {} but the network predicts {}'.format(
                         scale, (C, H, W), expect))
                 targets = self._targets(dmll)
+                if scale == 0 and defer_rgb is not None and dmll.rgb_scale:
+                    P_out = defer_rgb(B, H, W, P.shape[-1])
+                    P_out.copy_(P)       # (one pass over P: 189 MB per 768x512 image -- 0.1 ms; the classifier's last layer could write here directly)
+                    return _DeferredRGB(P_out, targets, streams, k, B, H, W, K, parsed.padding)
                 if dmll.rgb_scale:
                     sym = self._decode_rgb_pipelined(P, targets, (buf, offs, lens), B, C, K, H, W)
                 else:
@@ -524,21 +531,24 @@ class Bitcoding(object):
             self._lane_key = key
         return self._lane_streams
 
-    def decode_many(self, batches, on_batch=None, lanes=None, chain_cus=0, out_dtype=torch.int64):
+    RAGGED_GROUP = 32        # decode_many: images whose RGB scales are decoded together as one ragged batch
+
+    def decode_many(self, batches, on_batch=None, lanes=None, chain_cus=0, out_dtype=torch.int64, ragged=None):
         """batches: list of lists of `.l3c` byte strings; the files of ONE entry are equally sized (padded) images (a forward pass of
         `encode_many`), entries may differ in shape.  -> list, in the order given, of ((B_i,3,H_i,W_i) int64 on the GPU, padding tuples),
         or None per entry when `on_batch(index, pixels, padding)` consumes the results as they are enqueued (called under the stream
         that decodes the entry; then nothing is kept on the device).  The reference decodes a folder one file after the other
         (bitcoding.py:125-161 per file, multiscale_tester.py:353-381 over the folder).
-        STREAMING (round 6): entry i runs on lane i % lanes -- a main stream (get_P convolutions, bottleneck scales, RGB tables) and a side
-        stream (RGB chains) of its own -- so that the MFMA-bound convolutions of entry i + 1 run beside the latency-bound RGB chains
-        of entry i, which leave most of the machine idle (3 B wavefronts).  Within one entry the two cannot overlap: the chains need the
-        tables, the tables need P.  One host thread enqueues everything (an entry costs a few milliseconds of host time since the RGB
-        schedule is one library call); a lane's previous entry is waited for before its buffers are reused."""
-        # [measured, profiles/r06_decode_lanes_probe.log] batches of 128: two lanes 62-146 MPix/s (erratic: the lanes' long decoder launches
-        # and convolutions alias on the hardware queues) against 142-144 for one lane; with the chains on 64 CUs of their own 125-147 --
-        # the round-5 verdict's bar for keeping the overlap was 180: NOT kept for large batches.  Small batches are latency-bound (one image:
-        # 93 ms whatever the machine does) and scale with the lanes.
+        Small batches are LATENCY-bound (one 768x512 image: 93 ms whatever the machine does -- three 393 216-symbol chains, a wavefront
+        each), so a set of differently sized images needs many images in flight (round 6):
+          * LANES: entry i runs on lane i % lanes, a stream pair of its own -- up to the hardware queues' concurrency (8 lanes: 5.5x);
+          * RAGGED RGB (ragged=True, the default for small batches): the lanes stop before the RGB scale -- two thirds of an image's
+            latency --, and the RGB scales of up to RAGGED_GROUP images of DIFFERENT sizes run in lock step as ONE ragged batch
+            (l3c_decode_rgb_ragged: one table launch and one decoder launch per pipeline step for all of them), on a stream pair of
+            its own while the lanes work on the next group.
+        Large batches (>= 64 images) run one after the other: [measured, profiles/r06_decode_lanes_probe.log] batches of 128 on two lanes
+        62-146 MPix/s (erratic: the lanes' long decoder launches and convolutions alias on the hardware queues) against 142-144 for one
+        lane; with the chains on 64 CUs of their own 125-147 -- the round-5 verdict's bar for keeping that overlap was 180."""
         n = self.N_DECODE_LANES if lanes is None else int(lanes)
         if lanes is None and max(len(f) for f in batches) >= 64:
             n = 1
@@ -556,28 +566,117 @@ class Bitcoding(object):
         start = torch.cuda.Event()
         start.record(outer)
         lane_streams = self._lanes(n, chain_cus)
-        done = [None] * n
-        for i, files in enumerate(batches):
+        for main, _ in lane_streams:
+            main.wait_event(start)
+        use_ragged = (ragged is None or ragged) and all(len(f) < 64 for f in batches)
+        done = []
+
+        def finish(i, pixels, padding, stream):
+            if on_batch is not None:
+                on_batch(i, pixels, padding)
+            else:
+                pixels.record_stream(outer)
+                result[i] = (pixels, padding)
+
+        if not use_ragged:
+            for i, files in enumerate(batches):
+                main, side = lane_streams[i % n]
+                with torch.cuda.stream(main):
+                    self._lane_side = side
+                    try:
+                        pixels, padding = self.decode_batch(files, out_dtype)
+                    finally:
+                        self._lane_side = None
+                    finish(i, pixels, padding, main)
+                    done.append(main.record_event())
+        else:
+            if getattr(self, '_rgb_streams', None) is None:
+                self._rgb_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            rgb_main, rgb_side = self._rgb_streams
+            rgb_main.wait_event(start)
+            group, n_img = [], 0
+            for i, files in enumerate(batches):
+                group.append((i, files))
+                n_img += len(files)
+                if n_img >= self.RAGGED_GROUP or i + 1 == len(batches):
+                    self._decode_group_ragged(group, lane_streams, rgb_main, rgb_side, out_dtype, finish)
+                    group, n_img = [], 0
+            done.append(rgb_main.record_event())
+        for ev in done:
+            outer.wait_event(ev)
+        return result
+
+    def _decode_group_ragged(self, group, lane_streams, rgb_main, rgb_side, out_dtype, finish):
+        """One group of decode_many's ragged form: the entries' coarse scales and P of the RGB scale on the lanes, then ALL their RGB scales
+        as one ragged batch on (rgb_main, rgb_side)."""
+        n = len(lane_streams)
+        sizes = []
+        for _, files in group:                       # (H, W) of the padded image from the file's own header: the last record's shape
+            _, H, W = parse_containers(files[:1]).scales[-1]
+            sizes.append((len(files), H, W))
+        Kp = 4 * 3 * self.blueprint.net.config_ms.prob.K
+        hws = [H * W for B, H, W in sizes for _ in range(B)]
+        total = sum(hws)
+        pixbase, p = [], 0
+        for B, H, W in sizes:
+            pixbase.append(p)
+            p += B * H * W
+        with torch.cuda.stream(rgb_main):
+            P_rag = torch.empty(total * Kp, dtype=torch.float32, device='cuda')
+            sym_rag = torch.zeros(3 * total, dtype=torch.int16, device='cuda')
+            alloc_done = rgb_main.record_event()
+        deferred, small = [], []
+        for g, (i, files) in enumerate(group):
             main, side = lane_streams[i % n]
-            if i < n:
-                main.wait_event(start)
+            main.wait_event(alloc_done)
+            P_rag.record_stream(main)
             with torch.cuda.stream(main):
                 self._lane_side = side
                 try:
-                    pixels, padding = self.decode_batch(files, out_dtype)
+                    d = self.decode_batch(files, out_dtype, defer_rgb=lambda B, H, W, kp, g=g: P_rag[pixbase[g] * Kp:(pixbase[g] + B * H * W) * Kp].view(B, H, W, kp))
                 finally:
                     self._lane_side = None
-                if on_batch is not None:
-                    on_batch(i, pixels, padding)
-                else:
-                    pixels.record_stream(outer)
-                    result[i] = (pixels, padding)
-                done[i % n] = torch.cuda.Event()
-                done[i % n].record(main)
-        for ev in done:
-            if ev is not None:
-                outer.wait_event(ev)
-        return result
+                if not isinstance(d, _DeferredRGB):      # (a model without an RGB scale 0 cannot occur; kept for safety)
+                    finish(i, d[0], d[1], main)
+                    continue
+                assert (d.B, d.H, d.W) == sizes[g], ((d.B, d.H, d.W), sizes[g])
+                deferred.append((g, i, d))
+                rgb_main.wait_event(main.record_event())
+        if not deferred:
+            return
+        import numpy as np
+        K = deferred[0][2].K
+        # one stream table for the whole group: CHANNEL-major over all images; every batch keeps its own stream buffer, addressed from the lowest one
+        base_t = min((d.streams.buf for _, _, d in deferred), key=lambda t: t.data_ptr())
+        Btot = len(hws)
+        offs = np.zeros((3, Btot), dtype=np.int64)
+        lens = np.zeros((3, Btot), dtype=np.int32)
+        b0 = 0
+        for g, i, d in deferred:
+            o, l = d.streams.scale_host(d.k)                              # (3 * B,) channel-major within the batch
+            delta = d.streams.buf.data_ptr() - base_t.data_ptr()
+            offs[:, b0:b0 + d.B] = o.reshape(3, d.B) + delta
+            lens[:, b0:b0 + d.B] = l.reshape(3, d.B)
+            b0 += d.B
+        min_hw = min(hws)
+        mode = {'never': 0, 'auto': 1, 'always': 2}[self.rgb_window]
+        probe = self.RGB_PROBE if (self.rgb_window == 'auto' and min_hw >= 16 * self.RGB_PROBE) else 0
+        n_regular = max(1, min(self.RGB_CHUNKS, (min_hw - 2 * probe) // 4096))
+        pix0, npix = ops.ragged_rgb_plan(hws, n_regular, probe)
+        overlap = Btot >= 16 if self.decode_overlap is None else bool(self.decode_overlap)
+        with torch.cuda.stream(rgb_main):
+            for _, _, d in deferred:
+                d.streams.buf.record_stream(rgb_main)
+                d.streams.buf.record_stream(rgb_side)
+            offs_d = ops.upload_small(offs.reshape(-1))
+            lens_d = ops.upload_small(lens.reshape(-1))
+            keep = ops.decode_rgb_ragged(P_rag, deferred[0][2].targets, sym_rag, base_t, offs_d, lens_d, hws, pix0, npix, K,
+                                         2 if overlap else 1, mode, rgb_side if overlap else None)
+            for g, i, d in deferred:
+                a = 3 * pixbase[g]
+                pixels = sym_rag[a:a + 3 * d.B * d.H * d.W].view(d.B, 3, d.H, d.W).to(out_dtype)
+                finish(i, pixels, d.padding, rgb_main)
+            del keep
 
     def _decode_z_scale(self, P, targets, streams, B, C, K, H, W):
         """A bottleneck scale: its C channels are independent given P, so ONE grouped table launch (fused, straight from P) and one
@@ -834,11 +933,23 @@ _UPLOAD_RING = _H2DRing(6)
 _UPLOAD_STREAM = [None]      # the files of a batch cross PCIe on a stream of their own: a lane's upload never queues behind that lane's previous batch
 
 
+class _DeferredRGB(object):
+    """A batch whose decode has stopped before the RGB scale (Bitcoding.decode_batch(defer_rgb=...)): P of that scale, its streams."""
+
+    def __init__(self, P, targets, streams, k, B, H, W, K, padding):
+        self.P, self.targets, self.streams, self.k, self.B, self.H, self.W, self.K, self.padding = P, targets, streams, k, B, H, W, K, padding
+
+
 class _DeviceStreams(object):
     """The entropy-coded streams of a batch of files on the device, 4-byte aligned and zero padded, all scales in one buffer."""
 
-    def __init__(self, buf, offs, lens, first, count):
+    def __init__(self, buf, offs, lens, first, count, offs_host=None, lens_host=None):
         self.buf, self.offs, self.lens, self.first, self.count = buf, offs, lens, first, count
+        self.offs_host, self.lens_host = offs_host, lens_host       # (numpy: the set decoder merges the tables of several batches on the host)
+
+    def scale_host(self, k):
+        a, n = self.first[k], self.count[k]
+        return self.offs_host[a:a + n], self.lens_host[a:a + n]
 
     def scale(self, k):
         """(buffer, offsets int64, lengths int32) of scale record k: the coarsest record in image-major order (stream b * C + c, what
@@ -893,7 +1004,7 @@ def _upload_streams(files, parsed):
     len_d = dev[table_at + 16 * S:table_at + 20 * S].view(torch.int32)
     out = torch.empty(int(padded.sum()), dtype=torch.uint8, device='cuda')
     ops.container_read(dev, src_d, dst_d, len_d, int(lens.max()), out)
-    return _DeviceStreams(out, dst_d, len_d, first, count)
+    return _DeviceStreams(out, dst_d, len_d, first, count, dst, lens)
 
 
 def count_scale_records(data):

@@ -839,7 +839,45 @@ struct DecodeArgs {
     int16_t *sym_out;
     int64_t sym_stride, sym_offset;   // stream s writes sym_out[s * sym_stride + sym_offset + i]
     WindowCtx win;                 // window rows (round 5): win.stats_in == nullptr -> classic rows
+    // RAGGED batches (round 6, l3c_decode_rgb_ragged: streams of DIFFERENT lengths -- images of different sizes -- in one launch; null = every
+    // stream n_sym symbols, rows at s * n_sym * Lp, output at s * sym_stride + sym_offset): per stream s its symbol count of this chunk, the
+    // byte offset of its rows inside `cdf`, its image's first pixel / pixel count / this chunk's first pixel (the output goes to
+    // sym_out + r_C * r_pixbase[s] + r_c * r_hw[s] + r_pix0[s]; the window context's P / sym are offset likewise)
+    const int64_t *r_npix, *r_table_off, *r_pixbase, *r_hw, *r_pix0;
+    int r_C, r_c;
 };
+
+// the stream's view of a part: rectangular or ragged
+struct StreamView {
+    uint32_t n_sym;
+    uint64_t rows;                 // address of the stream's first row
+    int16_t *dst;
+    WindowCtx win;                 // (P, sym, HW, pix0 of THIS stream's image when ragged; index the image as 0 then)
+    int64_t img;                   // image index to hand to the window functions
+};
+__device__ __forceinline__ StreamView stream_view(const DecodeArgs &a, int64_t s) {
+    StreamView v;
+    v.win = a.win;
+    if (a.r_npix) {
+        const int64_t pb = a.r_pixbase[s], hw = a.r_hw[s], p0 = a.r_pix0[s];
+        v.n_sym = (uint32_t)a.r_npix[s];
+        v.rows = reinterpret_cast<uint64_t>(a.cdf) + (uint64_t)a.r_table_off[s];
+        v.dst = a.sym_out + a.r_C * pb + a.r_c * hw + p0;
+        if (a.win.stats_in) {
+            v.win.P = a.win.P + pb * (int64_t)(4 * a.win.C * a.win.K);
+            v.win.sym = a.win.sym ? a.win.sym + pb * a.win.C : nullptr;
+            v.win.HW = hw;
+            v.win.pix0 = p0;
+        }
+        v.img = 0;
+    } else {
+        v.n_sym = a.n_sym;
+        v.rows = reinterpret_cast<uint64_t>(a.cdf) + (uint64_t)s * a.n_sym * ((uint64_t)a.Lp * 2u);
+        v.dst = a.sym_out + s * a.sym_stride + a.sym_offset;
+        v.img = s;
+    }
+    return v;
+}
 
 // The GENERIC decoder: the reference's arithmetic literally (decode_symbol), for every stream when the table is not validated,
 // otherwise only for the streams the fast pass (ac_decode_lean_kernel, below) has marked by the sentinel -1 in the chunk's
@@ -860,21 +898,22 @@ __device__ __forceinline__ void ring_decode_body(const DecodeArgs &a, uint8_t *r
     using C = RingCfg<NJ, IPB_>;
     const uint16_t *cdf = a.cdf;
     const int64_t table_bytes = a.table_bytes;
-    const uint32_t n_sym = a.n_sym;
     const bool has_win = a.win.stats_in != nullptr;
     if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x]))) return;   // not this kernel's kind of stream
     const int Lp = WINDOW ? l3c::kWinLp : a.Lp;
     const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
     const int64_t s = blockIdx.x;
+    const StreamView sv = stream_view(a, s);
+    const uint32_t n_sym = sv.n_sym;
     const int lane = threadIdx.x;
     const int top = Lp - 2;
     const uint32_t row_bytes = (uint32_t)Lp * 2u;
     const uint32_t R = (uint32_t)ring_rows_per_block(Lp, C::BLOCK_BYTES);
     const uint32_t n_blocks = (n_sym + R - 1u) / R;
     const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
-    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * ((uint64_t)a.Lp * 2u);   // this stream's first row (its full-size slot)
+    const uint64_t stream0 = sv.rows;   // this stream's first row (its full-size slot)
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
-    int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
+    int16_t *dst = sv.dst;
     if (!a.force && validated && dst[0] != (int16_t)-1) return;   // decoded by the fast pass (ac_decode_lean_kernel)
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)ring;
 
@@ -955,7 +994,7 @@ __device__ __forceinline__ void ring_decode_body(const DecodeArgs &a, uint8_t *r
                 }
                 lds_row_take(row, pending);   // (before the long path: no LDS read in flight while the full row is evaluated)
                 if (need_full) {
-                    const Regs<4> full = window_full_row(a.win, s, a.win.pix0 + (int64_t)i, lane);
+                    const Regs<4> full = window_full_row(sv.win, sv.img, sv.win.pix0 + (int64_t)i, lane);
                     x = decode_symbol<4>(full, low, high, value, src, 255, validated && full_row_monotone(full, lane), i != no_advance);
                 }
                 keep_symbol(dst, i, n_sym, x, lane, kept);
@@ -1440,21 +1479,22 @@ __device__ __forceinline__ void lean_decode_body(const DecodeArgs &a, uint8_t *r
     // 0.415 vs 0.404 s per batch of 128)
     const uint16_t *cdf = a.cdf;
     const int64_t table_bytes = a.table_bytes;
-    const uint32_t n_sym = a.n_sym;
     const bool has_win = a.win.stats_in != nullptr;
     if (WINDOW != (has_win && l3c::use_window(a.win.stats_in[blockIdx.x]))) return;   // not this kernel's kind of stream
     const int Lp = WINDOW ? l3c::kWinLp : a.Lp;
     const bool validated = a.flag ? (*a.flag == 0) : (a.monotone != 0);
     const int64_t s = blockIdx.x;
+    const StreamView sv = stream_view(a, s);
+    const uint32_t n_sym = sv.n_sym;
     const int lane = threadIdx.x;
     const uint32_t top = (uint32_t)(Lp - 2);
     const uint32_t row_bytes = (uint32_t)Lp * 2u;
     const uint32_t R = (uint32_t)ring_rows_per_block(Lp, C::BLOCK_BYTES) & ~1u;   // even: the loop below takes rows in pairs
     const uint32_t n_blocks = (n_sym + R - 1u) / R;
     const uint64_t tab0 = reinterpret_cast<uint64_t>(cdf);
-    const uint64_t stream0 = tab0 + (uint64_t)s * n_sym * ((uint64_t)a.Lp * 2u);   // this stream's first row (its full-size slot)
+    const uint64_t stream0 = sv.rows;   // this stream's first row (its full-size slot)
     const uint64_t last_granule = (tab0 + (uint64_t)table_bytes - 1u) & ~(uint64_t)15;
-    int16_t *dst = a.sym_out + s * a.sym_stride + a.sym_offset;
+    int16_t *dst = sv.dst;
     if (!validated) {   // not a table for the fast path: leave the whole chunk to the generic pass
         if (lane == 0) dst[0] = (int16_t)-1;
         return;
@@ -1566,12 +1606,12 @@ __device__ __forceinline__ void lean_decode_body(const DecodeArgs &a, uint8_t *r
         if (__builtin_expect(miss != 0, 0)) {                                                                              \
             /* further windows of the same pixel's row, 62 symbols on in the direction of the miss (so that the symbol next to the old */ \
             /* window is inside the new one), until the symbol is inside: the direction never turns, the alphabet's ends are exact */ \
-            const LaneMixture lm = window_lane_mixture(a.win, s, a.win.pix0 + (int64_t)(i0 + (J)), lane);                  \
+            const LaneMixture lm = window_lane_mixture(sv.win, sv.img, sv.win.pix0 + (int64_t)(i0 + (J)), lane);           \
             int wb = (int)w0_j;                                                                                            \
             do {                                                                                                           \
                 wb = miss > 0 ? (wb + 62 < l3c::kWinMaxOffset ? wb + 62 : l3c::kWinMaxOffset) : (wb > 62 ? wb - 62 : 0);    \
                 bool mono;                                                                                                 \
-                const RowHi<1> rw = window_row_at(a.win, lm, wb, lane, mono);                                              \
+                const RowHi<1> rw = window_row_at(sv.win, lm, wb, lane, mono);                                             \
                 if (!mono) {                                                                                               \
                     st.bad = 1u;   /* a row the fast pass must not rank: the generic pass decodes this chunk */            \
                     break;                                                                                                 \
@@ -1948,15 +1988,20 @@ int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_strea
         L3C_REQUIRE(q.Lp >= 2 && q.Lp <= 257, "Lp out of range (2..257)");
         L3C_REQUIRE((q.Lp - 1 <= 64) == (parts[0].Lp - 1 <= 64), "parts of one call must share the alphabet class (Lp <= 65 or not)");
         L3C_REQUIRE((q.not_monotone_flag != nullptr) == (parts[0].not_monotone_flag != nullptr), "parts must agree on having a validity flag");
+        const bool ragged = q.r_npix != nullptr;
         L3C_REQUIRE(q.n_streams > 0 && q.n_sym > 0 && q.n_sym < (1ll << 31), "bad shape");
-        L3C_REQUIRE(q.sym_offset >= 0 && q.sym_stride >= q.n_sym, "bad output layout");
+        L3C_REQUIRE(ragged || (q.sym_offset >= 0 && q.sym_stride >= q.n_sym), "bad output layout");
+        L3C_REQUIRE(!ragged || (q.r_table_off && q.r_pixbase && q.r_hw && q.r_pix0 && q.r_C > 0 && q.r_c >= 0 && q.r_c < q.r_C && q.r_table_bytes > 0),
+                    "ragged part: every per-stream array, the plane count and the table size are needed");
         L3C_REQUIRE((reinterpret_cast<uintptr_t>(q.in) & 3) == 0 && (reinterpret_cast<uintptr_t>(q.cdf) & 1) == 0, "misaligned input");
         L3C_REQUIRE(((reinterpret_cast<uintptr_t>(q.state_in) | reinterpret_cast<uintptr_t>(q.state_out)) & 7) == 0, "misaligned state");
         L3C_REQUIRE(q.state_in != q.state_out || !q.state_in, "state_in and state_out must differ (a marked stream is decoded twice)");
         DecodeArgs &a = pack.part[i];
         a.cdf = q.cdf;
         a.Lp = q.Lp;
-        a.table_bytes = q.n_streams * q.n_sym * (int64_t)q.Lp * 2;
+        a.table_bytes = ragged ? q.r_table_bytes : q.n_streams * q.n_sym * (int64_t)q.Lp * 2;
+        a.r_npix = q.r_npix;  a.r_table_off = q.r_table_off;  a.r_pixbase = q.r_pixbase;  a.r_hw = q.r_hw;  a.r_pix0 = q.r_pix0;
+        a.r_C = q.r_C;  a.r_c = q.r_c;
         a.in = q.in;
         a.in_offsets = q.in_offsets;
         a.in_nbytes = q.in_nbytes;
@@ -1974,7 +2019,7 @@ int l3c_ac_decode_chunks(const l3c_ac_decode_part *parts, int n_parts, l3c_strea
             L3C_REQUIRE(q.Lp == 257 && q.C == 3 && q.K > 0 && q.K <= 16 && q.c >= 0 && q.c < 3, "window rows: RGB scale only (Lp 257, C 3, K <= 16)");
             L3C_REQUIRE(q.P && q.targets && (q.c == 0 || q.sym_all), "window rows: P, targets and the decoded channels are needed to evaluate a missed row");
             L3C_REQUIRE(q.not_monotone_flag, "window rows: the table's validity flag is required");
-            L3C_REQUIRE(q.HW > 0 && q.pix0 >= 0 && q.pix0 + q.n_sym <= q.HW, "window rows: chunk outside the image");
+            L3C_REQUIRE(ragged || (q.HW > 0 && q.pix0 >= 0 && q.pix0 + q.n_sym <= q.HW), "window rows: chunk outside the image");
             a.win = WindowCtx{q.window_stats_in, q.window_stats_out, q.P, q.sym_all, q.targets, q.HW, q.pix0, q.C, q.K, q.c};
         }
     }

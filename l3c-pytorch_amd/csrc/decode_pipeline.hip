@@ -31,15 +31,17 @@ struct Layout {
     int64_t flags, states, stats, scratch, tables, table_bytes, state_bytes, total;
 };
 
-Layout layout(int64_t B, int64_t max_npix, int n_chunks, int lag) {
+// rectangular: B images, max_npix pixels in the longest chunk; ragged (streams > 0): B = 1, max_npix = the largest chunk's TOTAL over the images
+Layout layout(int64_t B, int64_t max_npix, int n_chunks, int lag, int64_t streams = 0) {
     Layout l{};
-    l.state_bytes = up(B * l3c_ac_decode_state_bytes());
+    const int64_t S = streams > 0 ? streams : B;
+    l.state_bytes = up(S * l3c_ac_decode_state_bytes());
     l.table_bytes = up(B * max_npix * LP * 2);
     int64_t p = 0;
     l.flags = p;    p += up(C3 * 4);
     l.states = p;   p += C3 * 2 * l.state_bytes;
-    l.stats = p;    p += up((int64_t)C3 * (n_chunks + 2) * B * 4);
-    l.scratch = p;  p += up(B * 4);
+    l.stats = p;    p += up((int64_t)C3 * (n_chunks + 2) * S * 4);
+    l.scratch = p;  p += up(S * 4);
     l.tables = p;   p += (lag == 2 ? 2 : 1) * C3 * l.table_bytes;
     l.total = p;
     return l;
@@ -84,26 +86,21 @@ int64_t l3c_decode_rgb_stats_offset(int64_t B, int64_t max_chunk_npix, int n_chu
     if (B <= 0 || max_chunk_npix <= 0 || n_chunks <= 0 || (lag != 1 && lag != 2)) return -1;
     return layout(B, max_chunk_npix, n_chunks, lag).stats;
 }
+}
 
-int l3c_decode_rgb(const l3c_rgb_decode_desc *d, l3c_stream_t main_stream, l3c_stream_t side_stream) {
-    L3C_REQUIRE(d, "null descriptor");
-    L3C_REQUIRE(d->P && d->targets && d->sym && d->in && d->in_offsets && d->in_nbytes && d->workspace, "null pointer in descriptor");
-    L3C_REQUIRE(d->B > 0 && d->B < 65536 && d->HW > 0 && d->K > 0 && d->K <= 16, "bad shape");
-    L3C_REQUIRE(d->n_chunks > 0 && d->n_chunks <= 4096 && d->chunk_pix0_host && d->chunk_npix_host, "bad chunk list");
-    L3C_REQUIRE(d->lag == 1 || d->lag == 2, "lag must be 1 (one stream) or 2 (tables and decoders overlapped on two streams)");
-    L3C_REQUIRE(d->lag == 1 || side_stream != main_stream, "lag 2 needs a side stream that is not the main stream");
-    L3C_REQUIRE(d->window_mode >= 0 && d->window_mode <= 2, "window_mode: 0 never, 1 auto, 2 always");
-    L3C_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & (ALIGN - 1)) == 0, "workspace must be 256-byte aligned");
-    int64_t max_npix = 0, next = 0;
-    for (int j = 0; j < d->n_chunks; ++j) {
-        L3C_REQUIRE(d->chunk_pix0_host[j] == next && d->chunk_npix_host[j] > 0, "chunks must tile [0, HW) in order");
-        L3C_REQUIRE(j + 1 == d->n_chunks || d->chunk_npix_host[j] % 64 == 0, "chunk boundaries must lie on the 64-symbol store blocks");
-        next += d->chunk_npix_host[j];
-        max_npix = d->chunk_npix_host[j] > max_npix ? d->chunk_npix_host[j] : max_npix;
-    }
-    L3C_REQUIRE(next == d->HW, "chunks must tile [0, HW) in order");
-    const Layout l = layout(d->B, max_npix, d->n_chunks, d->lag);
-    L3C_REQUIRE(d->workspace_bytes >= l.total, "workspace too small (l3c_decode_rgb_workspace_bytes)");
+namespace {
+
+// one schedule for both forms: `rag` == nullptr -> the rectangular batch of `d`
+struct Ragged {
+    const int64_t *hw_host;        // [B]
+    const int64_t *pix0_host;      // [n_chunks][B]
+    const int64_t *npix_host;      // [n_chunks][B]
+    const int64_t *tables_dev;     // pixbase [B] | hw [B] | pix0 [n_chunks][B] | npix [n_chunks][B] | table_off [n_chunks][B]
+};
+
+int decode_rgb_impl(const l3c_rgb_decode_desc *d, const Ragged *rag, int64_t max_npix, l3c_stream_t main_stream, l3c_stream_t side_stream) {
+    const Layout l = layout(rag ? 1 : d->B, max_npix, d->n_chunks, d->lag, rag ? d->B : 0);
+    L3C_REQUIRE(d->workspace_bytes >= l.total, "workspace too small (l3c_decode_rgb(_ragged)_workspace_bytes)");
     const hipStream_t main = l3c::as_stream(main_stream), side = d->lag == 2 ? l3c::as_stream(side_stream) : main;
     EventPool *pool = nullptr;
     int rc = events_for_current_device(&pool);
@@ -130,17 +127,38 @@ int l3c_decode_rgb(const l3c_rgb_decode_desc *d, l3c_stream_t main_stream, l3c_s
         if (rc == L3C_OK) rc = l3c::check_hip(hipStreamWaitEvent(side, ev_tables, 0), "hipStreamWaitEvent");
         if (rc != L3C_OK) return rc;
     }
+    l3c_ragged_batch rb{};
+    const int64_t *dev_pix0 = nullptr, *dev_npix = nullptr, *dev_off = nullptr;
+    if (rag) {
+        int64_t max_hw = 0;
+        for (int64_t b = 0; b < B; ++b) max_hw = rag->hw_host[b] > max_hw ? rag->hw_host[b] : max_hw;
+        rb = l3c_ragged_batch{B, max_hw, rag->tables_dev, rag->tables_dev + B};
+        dev_pix0 = rag->tables_dev + 2 * B;
+        dev_npix = dev_pix0 + (int64_t)n_ch * B;
+        dev_off = dev_npix + (int64_t)n_ch * B;
+    }
     const int n_steps = n_ch + D * (C3 - 1);
     int last_decoded = -1;
     for (int t = 0; t < n_steps; ++t) {
         l3c_table_part tp[C3];
+        l3c_ragged_part rp[C3];
         l3c_ac_decode_part dp[C3];
         int n = 0;
         uint8_t *slot = ws + l.tables + (D == 2 ? (t & 1) : 0) * C3 * l.table_bytes;
         for (int c = 0; c < C3; ++c) {
             const int j = t - D * c;
             if (j < 0 || j >= n_ch) continue;
-            const int64_t p0 = d->chunk_pix0_host[j], np = d->chunk_npix_host[j];
+            int64_t p0 = 0, np = 0, total = 0;
+            if (rag) {
+                for (int64_t b = 0; b < B; ++b) {
+                    const int64_t nb = rag->npix_host[(int64_t)j * B + b];
+                    np = nb > np ? nb : np;
+                    total += nb;
+                }
+            } else {
+                p0 = d->chunk_pix0_host[j];
+                np = d->chunk_npix_host[j];
+            }
             uint16_t *table = reinterpret_cast<uint16_t *>(slot + c * l.table_bytes);
             int32_t *st_in = d->window_mode ? stats + ((int64_t)c * (n_ch + 2) + j) * B : nullptr;
             int32_t *st_out = d->window_mode == 2 ? scratch : d->window_mode == 1 ? stats + ((int64_t)c * (n_ch + 2) + j + 2) * B : nullptr;
@@ -161,6 +179,17 @@ int l3c_decode_rgb(const l3c_rgb_decode_desc *d, l3c_stream_t main_stream, l3c_s
             q.sym_out = d->sym;
             q.sym_stride = C3 * HW;
             q.sym_offset = c * HW + p0;
+            if (rag) {
+                rp[n] = l3c_ragged_part{dev_pix0 + (int64_t)j * B, dev_npix + (int64_t)j * B, dev_off + (int64_t)j * B};
+                q.r_npix = rp[n].npix;
+                q.r_table_off = rp[n].table_off;
+                q.r_pixbase = rb.pixbase;
+                q.r_hw = rb.hw;
+                q.r_pix0 = rp[n].pix0;
+                q.r_C = C3;
+                q.r_c = c;
+                q.r_table_bytes = total * LP * 2;
+            }
             if (d->window_mode) {
                 q.window_stats_in = st_in;
                 q.window_stats_out = st_out;
@@ -180,7 +209,8 @@ int l3c_decode_rgb(const l3c_rgb_decode_desc *d, l3c_stream_t main_stream, l3c_s
             rc = l3c::check_hip(hipStreamWaitEvent(main, ev_decoded[(t - 2) % 3], 0), "hipStreamWaitEvent");
             if (rc != L3C_OK) return rc;
         }
-        rc = l3c_dmll_cdf_table_parts(d->P, d->sym, d->targets, B, HW, C3, d->K, 1, LP, tp, n, main);
+        rc = rag ? l3c_dmll_cdf_table_ragged(d->P, d->sym, d->targets, &rb, C3, d->K, 1, LP, tp, rp, n, main)
+                 : l3c_dmll_cdf_table_parts(d->P, d->sym, d->targets, B, HW, C3, d->K, 1, LP, tp, n, main);
         if (rc != L3C_OK) return rc;
         if (D == 2) {
             rc = l3c::check_hip(hipEventRecord(ev_tables, main), "hipEventRecord");
@@ -200,5 +230,69 @@ int l3c_decode_rgb(const l3c_rgb_decode_desc *d, l3c_stream_t main_stream, l3c_s
         if (rc != L3C_OK) return rc;
     }
     return L3C_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int l3c_decode_rgb(const l3c_rgb_decode_desc *d, l3c_stream_t main_stream, l3c_stream_t side_stream) {
+    L3C_REQUIRE(d, "null descriptor");
+    L3C_REQUIRE(d->P && d->targets && d->sym && d->in && d->in_offsets && d->in_nbytes && d->workspace, "null pointer in descriptor");
+    L3C_REQUIRE(d->B > 0 && d->B < 65536 && d->HW > 0 && d->K > 0 && d->K <= 16, "bad shape");
+    L3C_REQUIRE(d->n_chunks > 0 && d->n_chunks <= 4096 && d->chunk_pix0_host && d->chunk_npix_host, "bad chunk list");
+    L3C_REQUIRE(d->lag == 1 || d->lag == 2, "lag must be 1 (one stream) or 2 (tables and decoders overlapped on two streams)");
+    L3C_REQUIRE(d->lag == 1 || side_stream != main_stream, "lag 2 needs a side stream that is not the main stream");
+    L3C_REQUIRE(d->window_mode >= 0 && d->window_mode <= 2, "window_mode: 0 never, 1 auto, 2 always");
+    L3C_REQUIRE((reinterpret_cast<uintptr_t>(d->workspace) & (ALIGN - 1)) == 0, "workspace must be 256-byte aligned");
+    int64_t max_npix = 0, next = 0;
+    for (int j = 0; j < d->n_chunks; ++j) {
+        L3C_REQUIRE(d->chunk_pix0_host[j] == next && d->chunk_npix_host[j] > 0, "chunks must tile [0, HW) in order");
+        L3C_REQUIRE(j + 1 == d->n_chunks || d->chunk_npix_host[j] % 64 == 0, "chunk boundaries must lie on the 64-symbol store blocks");
+        next += d->chunk_npix_host[j];
+        max_npix = d->chunk_npix_host[j] > max_npix ? d->chunk_npix_host[j] : max_npix;
+    }
+    L3C_REQUIRE(next == d->HW, "chunks must tile [0, HW) in order");
+    return decode_rgb_impl(d, nullptr, max_npix, main_stream, side_stream);
+}
+
+int64_t l3c_decode_rgb_ragged_workspace_bytes(int64_t B, int64_t max_chunk_total_npix, int n_chunks, int lag) {
+    if (B <= 0 || max_chunk_total_npix <= 0 || n_chunks <= 0 || (lag != 1 && lag != 2)) return -1;
+    return layout(1, max_chunk_total_npix, n_chunks, lag, B).total;
+}
+
+int l3c_decode_rgb_ragged(const l3c_rgb_ragged_desc *r, l3c_stream_t main_stream, l3c_stream_t side_stream) {
+    L3C_REQUIRE(r, "null descriptor");
+    L3C_REQUIRE(r->P && r->targets && r->sym && r->in && r->in_offsets && r->in_nbytes && r->workspace && r->hw_host && r->tables_dev,
+                "null pointer in descriptor");
+    L3C_REQUIRE(r->B > 0 && r->B < 65536 && r->K > 0 && r->K <= 16, "bad shape");
+    L3C_REQUIRE(r->n_chunks > 0 && r->n_chunks <= 4096 && r->chunk_pix0_host && r->chunk_npix_host, "bad chunk list");
+    L3C_REQUIRE(r->lag == 1 || r->lag == 2, "lag must be 1 (one stream) or 2 (tables and decoders overlapped on two streams)");
+    L3C_REQUIRE(r->lag == 1 || side_stream != main_stream, "lag 2 needs a side stream that is not the main stream");
+    L3C_REQUIRE(r->window_mode >= 0 && r->window_mode <= 2, "window_mode: 0 never, 1 auto, 2 always");
+    L3C_REQUIRE((reinterpret_cast<uintptr_t>(r->workspace) & (ALIGN - 1)) == 0, "workspace must be 256-byte aligned");
+    int64_t max_total = 0;
+    for (int64_t b = 0; b < r->B; ++b) {
+        int64_t next = 0;
+        for (int j = 0; j < r->n_chunks; ++j) {
+            const int64_t p0 = r->chunk_pix0_host[(int64_t)j * r->B + b], np = r->chunk_npix_host[(int64_t)j * r->B + b];
+            L3C_REQUIRE(p0 == next && np > 0, "every image's chunks must tile [0, HW_b) in order, none empty");
+            L3C_REQUIRE(j + 1 == r->n_chunks || np % 64 == 0, "chunk boundaries must lie on the 64-symbol store blocks");
+            next += np;
+        }
+        L3C_REQUIRE(next == r->hw_host[b], "every image's chunks must tile [0, HW_b) in order");
+    }
+    for (int j = 0; j < r->n_chunks; ++j) {
+        int64_t total = 0;
+        for (int64_t b = 0; b < r->B; ++b) total += r->chunk_npix_host[(int64_t)j * r->B + b];
+        max_total = total > max_total ? total : max_total;
+    }
+    l3c_rgb_decode_desc d{};
+    d.P = r->P;  d.targets = r->targets;  d.sym = r->sym;  d.B = r->B;  d.HW = 0;  d.K = r->K;
+    d.in = r->in;  d.in_offsets = r->in_offsets;  d.in_nbytes = r->in_nbytes;
+    d.n_chunks = r->n_chunks;  d.lag = r->lag;  d.window_mode = r->window_mode;
+    d.workspace = r->workspace;  d.workspace_bytes = r->workspace_bytes;
+    const Ragged rag{r->hw_host, r->chunk_pix0_host, r->chunk_npix_host, r->tables_dev};
+    return decode_rgb_impl(&d, &rag, max_total, main_stream, side_stream);
 }
 }

@@ -201,9 +201,13 @@ struct TablePart {
     uint16_t *cdf;
     int32_t *not_monotone;
     const int32_t *win_stats;
+    // RAGGED batches (round 6, l3c_decode_rgb_ragged: images of DIFFERENT sizes in one launch; null = every image [HW] pixels, rows
+    // [range0, range0 + range_len)): per image b its pixel range of this part and the byte offset of its rows inside `cdf`
+    const int64_t *r_pix0, *r_npix, *r_table_off;
 };
 struct TableParts {
     TablePart part[kMaxTableParts];
+    const int64_t *r_pixbase, *r_hw;   // ragged: image b's pixels start at pixel r_pixbase[b] of P (and its C planes at element C * r_pixbase[b] of sym), it has r_hw[b] of them
 };
 
 __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__restrict__ P, const int16_t *__restrict__ sym,
@@ -215,20 +219,26 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
     __shared__ float s_t[260];
     const TablePart &part = parts.part[blockIdx.z];
     const int c = part.c;
-    const int64_t range0 = part.range0, range_len = part.range_len;
-    uint16_t *__restrict__ cdf = part.cdf;
     int32_t *__restrict__ not_monotone = part.not_monotone;
     const int32_t *__restrict__ win_stats = part.win_stats;
     const int Kp = (rgb ? 4 : 3) * C * K;
     const int ld = Kp + 1;
     const int64_t b = blockIdx.y;
+    // image b: its pixels in P / sym, its range of this part, its rows in the table -- a rectangular batch, or a RAGGED one (per-image arrays)
+    const bool ragged = parts.r_hw != nullptr;
+    if (ragged) HW = parts.r_hw[b];
+    const int64_t img_pix = ragged ? parts.r_pixbase[b] : b * HW;
+    const int64_t range0 = ragged ? part.r_pix0[b] : part.range0, range_len = ragged ? part.r_npix[b] : part.range_len;
+    uint16_t *__restrict__ cdf = ragged ? part.cdf + (part.r_table_off[b] >> 1) : part.cdf + b * range_len * Lp;   // this image's rows (its full-size slot)
+    P += img_pix * Kp;
+    if (sym) sym += img_pix * C;
     const int64_t off = (int64_t)blockIdx.x * kTablePix;          // offset inside the range
-    if (off >= range_len) return;                                 // (uniform: a shorter part of a grouped launch)
+    if (off >= range_len) return;                                 // (uniform: a shorter part of a grouped launch, a smaller image of a ragged one)
     const int64_t pix0 = range0 + off;
     const int npix = (int)((range_len - off) < kTablePix ? (range_len - off) : kTablePix);
     const int tid = threadIdx.x;
     const bool window = win_stats && l3c::use_window(win_stats[b]);   // uniform over the image's blocks
-    const float *src = P + (b * HW + pix0) * Kp;
+    const float *src = P + pix0 * Kp;
     fill_tile<256>(tile, src, npix, Kp, ld, dv, tid);
     for (int i = tid; i < Lp; i += 256) s_t[i] = targets[i];
     __syncthreads();
@@ -254,8 +264,8 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
             const int64_t n = pix0 + p;
             float x0 = 0.f, x1 = 0.f;
             if (rgb && c > 0) {
-                x0 = (float)sym[(b * C + 0) * HW + n];
-                if (c > 1) x1 = (float)sym[(b * C + 1) * HW + n];
+                x0 = (float)sym[0 * HW + n];
+                if (c > 1) x1 = (float)sym[1 * HW + n];
             }
             MixStats st;
             st.max_logit = s_max[p];
@@ -298,7 +308,7 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
             uint32_t v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = cdf_quantise(acc[i], scale, l0 + i);
-            uint16_t *row = cdf + b * range_len * Lp + (off + p) * l3c::kWinLp + q * 8;
+            uint16_t *row = cdf + (off + p) * l3c::kWinLp + q * 8;
 #pragma unroll
             for (int i = 0; i < 8; ++i) row[i] = (uint16_t)v[i];
             if (q == 7) row[8] = (uint16_t)w0;          // entry 64: the window's offset
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) void cdf_table_from_P_kernel(const float *__re
         return;
     }
     const int count = npix * Lp;
-    uint16_t *out = cdf + (b * range_len + off) * Lp;
+    uint16_t *out = cdf + off * Lp;
     const bool aligned4 = ((reinterpret_cast<uintptr_t>(out) & 3) == 0);
     // The strict-monotonicity check the decoder needs (l3c_cdf_check_monotone: entries 0 .. Lp-2 of every row) is done on the
     // entries while they are in registers instead of re-reading the table (a 24 GB pass per batch of 128 otherwise): a thread
@@ -581,7 +591,8 @@ int l3c_cdf_table_mixture(const float *targets, const float *pi, const float *mu
 }
 
 static int cdf_table_parts_launch(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
-                                  int Lp, const l3c_table_part *parts, int n_parts, l3c_stream_t stream) {
+                                  int Lp, const l3c_table_part *parts, int n_parts, l3c_stream_t stream, const l3c_ragged_batch *rag = nullptr,
+                                  const l3c_ragged_part *rag_parts = nullptr) {
     L3C_REQUIRE(P && targets && parts, "null pointer");
     L3C_REQUIRE(n_parts > 0 && n_parts <= kMaxTableParts, "1..8 parts per call");
     L3C_REQUIRE(B > 0 && B < 65536 && HW > 0 && C > 0, "bad shape");
@@ -597,11 +608,22 @@ static int cdf_table_parts_launch(const float *P, const int16_t *sym, const floa
         const l3c_table_part &q = parts[i];
         L3C_REQUIRE(q.cdf, "null table pointer in part");
         L3C_REQUIRE(q.c >= 0 && q.c < C, "channel out of range");
-        L3C_REQUIRE(q.pix0 >= 0 && q.npix > 0 && q.pix0 + q.npix <= HW, "pixel range outside the image");
+        L3C_REQUIRE(rag || (q.pix0 >= 0 && q.npix > 0 && q.pix0 + q.npix <= HW), "pixel range outside the image");
         L3C_REQUIRE(!(rgb && q.c > 0) || sym, "the RGB scale needs the symbols of the channels decoded so far");
         L3C_REQUIRE(!q.window_stats || Lp == 257, "window rows are defined for the 256-symbol alphabet (Lp == 257)");
-        tp.part[i] = TablePart{q.c, q.pix0, q.npix, q.cdf, q.not_monotone, q.window_stats};
+        tp.part[i] = TablePart{q.c, q.pix0, q.npix, q.cdf, q.not_monotone, q.window_stats, nullptr, nullptr, nullptr};
+        if (rag) {      // q.npix = the LONGEST range of the part (it sizes the grid); the per-image ranges come from the device arrays
+            L3C_REQUIRE(rag_parts && rag_parts[i].pix0 && rag_parts[i].npix && rag_parts[i].table_off, "ragged part without its arrays");
+            tp.part[i].r_pix0 = rag_parts[i].pix0;
+            tp.part[i].r_npix = rag_parts[i].npix;
+            tp.part[i].r_table_off = rag_parts[i].table_off;
+        }
         longest = q.npix > longest ? q.npix : longest;
+    }
+    if (rag) {
+        L3C_REQUIRE(rag->pixbase && rag->hw, "ragged batch without its arrays");
+        tp.r_pixbase = rag->pixbase;
+        tp.r_hw = rag->hw;
     }
     const dim3 grid((unsigned)((longest + kTablePix - 1) / kTablePix), (unsigned)B, (unsigned)n_parts);
     hipLaunchKernelGGL(cdf_table_from_P_kernel, grid, dim3(256), lds, l3c::as_stream(stream), P, sym, targets, HW, C, K, rgb, Lp, tp,
@@ -620,6 +642,14 @@ int l3c_dmll_cdf_table(const float *P, const int16_t *sym, const float *targets,
 int l3c_dmll_cdf_table_parts(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C, int K, int rgb,
                              int Lp, const l3c_table_part *parts_host, int n_parts, l3c_stream_t stream) {
     return cdf_table_parts_launch(P, sym, targets, B, HW, C, K, rgb, Lp, parts_host, n_parts, stream);
+}
+
+int l3c_dmll_cdf_table_ragged(const float *P, const int16_t *sym, const float *targets, const l3c_ragged_batch *batch, int C, int K, int rgb,
+                              int Lp, const l3c_table_part *parts_host, const l3c_ragged_part *ragged_parts_host, int n_parts,
+                              l3c_stream_t stream) {
+    L3C_REQUIRE(batch && ragged_parts_host, "null pointer");
+    L3C_REQUIRE(batch->B > 0 && batch->max_hw > 0, "bad ragged batch");
+    return cdf_table_parts_launch(P, sym, targets, batch->B, batch->max_hw, C, K, rgb, Lp, parts_host, n_parts, stream, batch, ragged_parts_host);
 }
 
 int l3c_dmll_encode_intervals(const float *P, const int16_t *sym, const float *targets, int64_t B, int64_t HW, int C,

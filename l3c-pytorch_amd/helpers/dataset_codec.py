@@ -210,7 +210,7 @@ def plan_decode_set(files, order, max_batch):
     return chunks, padded
 
 
-def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus=0, n_pinned=None):
+def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus=0, n_pinned=None, ragged=None):
     """files: {index: `.l3c` bytes} (as `encode_set` returns them); order: the indices to decode.  -> {index: uint8 (3,H,W) HOST tensor},
     the padding undone.  The mirror of `encode_set` for the reference's folder evaluation, which decodes EVERY file it wrote and
     compares it with the input (multiscale_tester.py:353-381, assert_equal at :373): files of equal padded shape share a batch,
@@ -225,7 +225,7 @@ def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus
 
     n_lanes = bc.N_DECODE_LANES if lanes is None else int(lanes)
     if n_pinned is None:
-        n_pinned = n_lanes + 2          # a lane's finished batch must never wait for a free D2H buffer
+        n_pinned = max(n_lanes, bc.RAGGED_GROUP) + 2          # a finished batch must never wait for a free D2H buffer (a ragged group finishes all its batches at once)
     chunks, padded = plan_decode_set(files, order, max_batch)
     by_size = sorted(range(len(chunks)), key=lambda k: -len(chunks[k]) * padded[k][0] * padded[k][1])
     mark('plan (host)')
@@ -251,7 +251,7 @@ def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus
         collect(True, keep=n_pinned - 1)                  # the buffer about to be reused must have been read out
         k = turn[0] = (turn[0] + 1) % n_pinned
         if ring[k] is None or ring[k].numel() < u8.numel():
-            ring[k] = torch.empty(max(u8.numel(), 16 << 20), dtype=torch.uint8, pin_memory=True)
+            ring[k] = torch.empty(-(-u8.numel() // (1 << 20)) << 20, dtype=torch.uint8, pin_memory=True)
         host = ring[k][:u8.numel()].view(u8.shape)
         host.copy_(u8, non_blocking=True)
         ev = torch.cuda.Event()
@@ -260,7 +260,7 @@ def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus
         collect(False)
 
     bc.decode_many([[files[i] for i in chunks[ci]] for ci in by_size], on_batch=on_batch, lanes=lanes, chain_cus=chain_cus,
-                   out_dtype=torch.uint8)
+                   out_dtype=torch.uint8, ragged=ragged)
     collect(True)
     mark('parse + H2D + decode + D2H (pipelined)')
     return out

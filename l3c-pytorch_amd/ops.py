@@ -409,6 +409,80 @@ def decode_rgb(P_nhwc, targets, sym, buf, offs, lens, bounds, K, lag, window_mod
     return ws, stats
 
 
+_PINNED_SCRATCH = {'bufs': [None] * 4, 'events': [None] * 4, 'turn': 0}
+
+
+def upload_small(array):
+    """numpy array -> device tensor of the same dtype through a small ring of page-locked buffers (an H2D copy from pageable memory makes the
+    host wait for the stream): descriptor tables of a few KB."""
+    import numpy as np
+    a = np.ascontiguousarray(array)
+    r = _PINNED_SCRATCH
+    k = r['turn'] = (r['turn'] + 1) % len(r['bufs'])
+    if r['events'][k] is not None:
+        r['events'][k].synchronize()
+    n = a.nbytes
+    if r['bufs'][k] is None or r['bufs'][k].numel() < n:
+        r['bufs'][k] = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
+    r['bufs'][k].numpy()[:n] = a.view(np.uint8).reshape(-1)
+    dev = r['bufs'][k][:n].cuda(non_blocking=True)
+    r['events'][k] = torch.cuda.Event()
+    r['events'][k].record(torch.cuda.current_stream())
+    return dev.view(torch.from_numpy(a[:0]).dtype).reshape(a.shape)
+
+
+def ragged_rgb_plan(hws, n_regular, probe):
+    """Chunk plan of a RAGGED RGB decode (l3c_decode_rgb_ragged): every image gets the same NUMBER of chunks -- two probe chunks of `probe`
+    symbols (0: none) and n_regular regular ones, the image's own chunk length rounded DOWN to a multiple of 64 with the last chunk taking
+    the rest -- so that all images step through the pipeline together.  hws: pixels per image.  -> (pix0, npix) int64 arrays (n_chunks, B)."""
+    import numpy as np
+    B = len(hws)
+    n_chunks = n_regular + (2 if probe else 0)
+    pix0 = np.zeros((n_chunks, B), dtype=np.int64)
+    npix = np.zeros((n_chunks, B), dtype=np.int64)
+    for b, hw in enumerate(hws):
+        start, j = 0, 0
+        if probe:
+            pix0[0, b], npix[0, b], pix0[1, b], npix[1, b] = 0, probe, probe, probe
+            start, j = 2 * probe, 2
+        step = (hw - start) // n_regular // 64 * 64
+        assert step >= 64, 'image too small for {} chunks'.format(n_regular)
+        for k in range(n_regular):
+            pix0[j + k, b] = start + k * step
+            npix[j + k, b] = step if k + 1 < n_regular else hw - start - k * step
+    return pix0, npix
+
+
+def decode_rgb_ragged(P_ragged, targets, sym_ragged, buf, offs, lens, hws, pix0, npix, K, lag, window_mode, side_stream=None):
+    """The RGB scale of B images of DIFFERENT sizes in lock step (l3c_decode_rgb_ragged): P_ragged (sum HW, 120) fp32, sym_ragged int16
+    (3 * sum HW,) ZEROED (image b: its three planes from element 3 * pixbase[b]), streams CHANNEL-major in (buf, offs (3B,), lens (3B,)),
+    hws = pixels per image, (pix0, npix) = ragged_rgb_plan(...).  -> workspace tensor (kept alive by the caller until the stream is done)."""
+    import ctypes
+    import numpy as np
+    lib = _lib.load()
+    B, n = len(hws), pix0.shape[0]
+    hw = np.asarray(hws, dtype=np.int64)
+    pixbase = np.concatenate([[0], np.cumsum(hw)[:-1]]).astype(np.int64)
+    table_off = (np.cumsum(npix, axis=1) - npix) * (257 * 2)
+    tables = upload_small(np.concatenate([pixbase, hw, pix0.reshape(-1), npix.reshape(-1), table_off.reshape(-1)]).astype(np.int64))
+    max_total = int(npix.sum(axis=1).max())
+    nbytes = lib.l3c_decode_rgb_ragged_workspace_bytes(B, max_total, n, lag)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=P_ragged.device)
+    hw_c = (_lib.c_i64 * B)(*[int(v) for v in hw])
+    p0_c = (_lib.c_i64 * (n * B))(*[int(v) for v in pix0.reshape(-1)])
+    np_c = (_lib.c_i64 * (n * B))(*[int(v) for v in npix.reshape(-1)])
+    desc = _lib.RgbRaggedDesc(ptr(P_ragged, torch.float32), ptr(targets, torch.float32), ptr(sym_ragged, torch.int16), B,
+                              ctypes.cast(hw_c, ctypes.POINTER(_lib.c_i64)), K, ptr(buf, torch.uint8), ptr(offs, torch.int64),
+                              ptr(lens, torch.int32), n, ctypes.cast(p0_c, ctypes.POINTER(_lib.c_i64)),
+                              ctypes.cast(np_c, ctypes.POINTER(_lib.c_i64)), ptr(tables, torch.int64), lag, window_mode, ptr(ws), nbytes)
+    main = torch.cuda.current_stream()
+    if lag == 2:
+        for t in (P_ragged, targets, sym_ragged, buf, offs, lens, ws, tables):
+            t.record_stream(side_stream)
+    call('l3c_decode_rgb_ragged', ctypes.byref(desc), main.cuda_stream, side_stream.cuda_stream if lag == 2 else None)
+    return ws, tables
+
+
 def container_read(files_dev, src_off, dst_off, nbytes, max_nbytes, dst):
     """l3c_container_read: the streams of many raw `.l3c` files (one device buffer) -> 4-byte aligned, zero padded streams in `dst`."""
     call('l3c_container_read', ptr(files_dev, torch.uint8), ptr(src_off, torch.int64), ptr(dst_off, torch.int64), ptr(nbytes, torch.int32),

@@ -189,7 +189,7 @@ def test_decode_set_gives_back_every_image_of_an_encoded_set(l3c_checkpoint):
         assert files[i] == bc.encode_batch(x.cuda()).to_bytes([pt if isinstance(pt, tuple) else (0, 0, 0, 0)])[0], i
     plans = dataset_codec.plan_decode_set(files, order, 4)
     assert sorted(i for c in plans[0] for i in c) == order and max(len(c) for c in plans[0]) <= 4
-    for kw in (dict(), dict(lanes=1), dict(max_batch=1, lanes=3)):
+    for kw in (dict(), dict(lanes=1), dict(max_batch=1, lanes=3), dict(ragged=False), dict(max_batch=2, lanes=2)):
         back = dataset_codec.decode_set(bc, files, order, **({'max_batch': 4} | kw))
         assert sorted(back) == order
         for i in order:

@@ -63,11 +63,11 @@ def main():
     by = {}
     for r in rows:
         k = '{}x{}'.format(*r['size'])
-        d = by.setdefault(k, {'images': 0, 'oracle_decodes_hip_file': 0, 'hip_decodes_oracle_file': 0, 'files_identical': 0})
+        d = by.setdefault(k, {'images': 0, 'oracle_decodes_hip_file': 0, 'hip_decodes_oracle_file': 0, 'sizes_equal': 0})
         d['images'] += 1
         d['oracle_decodes_hip_file'] += r['oracle_decodes_hip_wrong_subpixels'] == 0
         d['hip_decodes_oracle_file'] += r['hip_decodes_oracle_wrong_subpixels'] == 0
-        d['files_identical'] += r['hip_bytes'] == r['oracle_bytes']
+        d['sizes_equal'] += r['hip_bytes'] == r['oracle_bytes']
     res = {'what': 'cross-implementation decode of .l3c files, calibrated checkpoint; counts of images decoded without a single wrong sub-pixel',
            'summary': by, 'seconds': round(time.time() - t0, 1), 'images': rows}
     os.makedirs(os.path.dirname(a.out), exist_ok=True)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Regenerate every profiles/r05_* evidence file (E) with ONE gpurun call (round-2 verdict: "make the evidence reproducible by command"):
+# Regenerate every profiles/r06_* evidence file (E) with ONE gpurun call (round-2 verdict: "make the evidence reproducible by command"):
 #
 #     /usr/local/graft/bin/gpurun --timeout 2400 -- tools/make_evidence.sh      # on the GPU box: writes gpurun_out/evidence/
-#     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r04_*
+#     tools/make_evidence.sh --collect                                          # here: copies the summaries to profiles/r06_*
 #     /usr/local/graft/bin/gpurun --timeout 900 -- tools/make_evidence.sh --bench-only   # the bench lines only (after host-side changes)
 #
 # Steps on the GPU box: (1) the default bench line (after the PMC passes, so that it carries their table); (2) the 768x512 parity suite (tests/test_gpu_headline.py writes the measured
@@ -11,7 +11,7 @@
 # profiled process launches exactly (warm-up + steps) identical steps; tools/pmc_bench.py keeps the launches of the timed steps only and
 # stamps the table with the hash of the kernel sources; two more passes over a decode-only command for the decode-side kernels;
 # (5) the other two configs at full size.
-R=r05
+R=r06
 if [ "$1" == "--collect" ]; then
     cd "$(dirname "$0")/.." || exit 1
     E=gpurun_out/evidence
@@ -30,6 +30,9 @@ if [ "$1" == "--collect" ]; then
     [ -f $E/parity_truth.json ] && cp $E/parity_truth.json profiles/${R}_parity_truth.json
     [ -f $E/decode_modes.log ] && cp $E/decode_modes.log profiles/${R}_decode_window_modes.log
     [ -f $E/pytest_gpu.log ] && cp $E/pytest_gpu.log profiles/${R}_pytest_gpu.log
+    [ -f $E/bench_files.json ] && cp $E/bench_files.json profiles/${R}_bench_files.json
+    [ -f $E/tcc_per_variant.json ] && cp $E/tcc_per_variant.json profiles/${R}_tcc_per_variant.json
+    [ -f $E/decode_concurrency_probe.log ] && cp $E/decode_concurrency_probe.log profiles/${R}_decode_concurrency_probe.log
     ls -la profiles/${R}_*
     exit 0
 fi
@@ -43,6 +46,7 @@ if [ "$1" == "--bench-only" ]; then
     timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err
     timeout 900 python bench.py --config dataset > $E/bench_dataset.json 2> $E/bench_dataset.err
     timeout 600 python bench.py --config large > $E/bench_large.json 2> $E/bench_large.err
+    timeout 900 python bench.py --config files > $E/bench_files.json 2> $E/bench_files.err
     tail -c 1200 $E/bench_default.json; cat $E/bench_dataset.json | cut -c1-300
     exit 0
 fi
@@ -78,7 +82,14 @@ cp $E/pmc_bench.json profiles/${R}_pmc_bench.json      # (the box's copy: the be
 timeout 900 python bench.py > $E/bench_default.json 2> $E/bench_default.err
 timeout 900 python bench.py --config dataset > $E/bench_dataset.json 2> $E/bench_dataset.err
 timeout 600 python bench.py --config large > $E/bench_large.json 2> $E/bench_large.err
+timeout 900 python bench.py --config files > $E/bench_files.json 2> $E/bench_files.err
+# L2 hit rates and memory-side bytes per kernel variant (round-5 verdict, next 1): TCC_HIT / TCC_MISS pass, joined with the FETCH / WRITE passes above
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $E/pmc_tcc/hm -o run --output-format csv -- python bench.py $PMCARGS > /dev/null 2> $E/pmc_tcc.err
+timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum -d $E/pmc_tcc/rd -o run --output-format csv -- python bench.py $PMCARGS > /dev/null 2>> $E/pmc_tcc.err
+[ -d $E/pmc ] && python tools/pmc_tcc.py $E/pmc_tcc $E/pmc > $E/tcc_per_variant.json 2>> $E/pmc_tcc.err
+rm -rf $E/pmc_tcc
+timeout 900 python tools/decode_concurrency_probe.py 2>&1 | grep -v amdgpu.ids > $E/decode_concurrency_probe.log
 # keep the merge-back small: the raw traces stay on the box
-rm -rf $E/stats $E/pmc $E/pmcd $E/dtrace
+rm -rf $E/stats $E/pmc $E/pmcd $E/dtrace $E/pmc_tcc
 ls -la $E
 tail -c 1500 $E/bench_default.json
