@@ -688,6 +688,10 @@ def run_dataset(args, ranks):
     # files of equal padded shape share a batch, the batches stream through Bitcoding.decode_many
     dec_seconds, lanes = [], int(os.environ.get('L3C_DECODE_LANES', '0')) or None
     ragged = {'0': False, '1': True}.get(os.environ.get('L3C_DECODE_RAGGED'))      # (development: A/B of the grouped RGB decode; None = the product's choice)
+    if os.environ.get('L3C_RAGGED_GROUP'):      # (development: images per ragged group)
+        bc.RAGGED_GROUP = int(os.environ['L3C_RAGGED_GROUP'])
+    if os.environ.get('L3C_RAGGED_MPIX'):       # (development: pixel budget of a ragged group)
+        bc.RAGGED_GROUP_PIXELS = int(os.environ['L3C_RAGGED_MPIX']) << 20
     for rep in range(3):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

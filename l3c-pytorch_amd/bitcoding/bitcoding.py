@@ -448,13 +448,10 @@ class Bitcoding(object):
         with torch.cuda.stream(first.coder_stream):
             on_group([(k, result[k]) for k in indices])
 
-    def decode_batch(self, files, out_dtype=torch.int64, defer_rgb=None):
+    def decode_batch(self, files, out_dtype=torch.int64):
         """files: list of B `.l3c` byte strings of equally sized (padded) images -> ((B,3,H,W) int64 on the GPU (the reference's
         dtype, bitcoding.py:125-161; out_dtype: torch.uint8 / int16 for callers that want the pixels without the 8-byte form),
         list of padding tuples).
-        defer_rgb (decode_many's grouped form): a callable (B, H, W, Kp) -> contiguous device tensor that P of the RGB scale is written
-        into; the call then stops BEFORE the RGB scale and returns a `_DeferredRGB` (the set decoder runs the RGB scales of many
-        batches of different shapes as ONE ragged batch).
         Round 6: the host only parses the FRAMING (a few length fields per file, `parse_containers`); the files cross PCIe as they
         are, in one copy from a page-locked buffer, and one kernel (l3c_container_read) cuts every stream out of them in the
         aligned, zero-padded form the range decoders read -- before, 14 `pack_streams` calls copied every payload on the host
@@ -495,10 +492,6 @@ class Bitcoding(object):
                     raise ValueError('invalid file: scale {} header (C, H, W) = {} but the network predicts {}'.format(
                         scale, (C, H, W), expect))
                 targets = self._targets(dmll)
-                if scale == 0 and defer_rgb is not None and dmll.rgb_scale:
-                    P_out = defer_rgb(B, H, W, P.shape[-1])
-                    P_out.copy_(P)       # (one pass over P: 189 MB per 768x512 image -- 0.1 ms; the classifier's last layer could write here directly)
-                    return _DeferredRGB(P_out, targets, streams, k, B, H, W, K, parsed.padding)
                 if dmll.rgb_scale:
                     sym = self._decode_rgb_pipelined(P, targets, (buf, offs, lens), B, C, K, H, W)
                 else:
@@ -531,7 +524,8 @@ class Bitcoding(object):
             self._lane_key = key
         return self._lane_streams
 
-    RAGGED_GROUP = 32        # decode_many: images whose RGB scales are decoded together as one ragged batch
+    RAGGED_GROUP = 512               # decode_many: at most this many images are decoded together as one ragged group ...
+    RAGGED_GROUP_PIXELS = 96 << 20   # ... and at most this many pixels (P of the RGB scale is 480 bytes per pixel: 48 GB; its tables 6 GB)
 
     def decode_many(self, batches, on_batch=None, lanes=None, chain_cus=0, out_dtype=torch.int64, ragged=None):
         """batches: list of lists of `.l3c` byte strings; the files of ONE entry are equally sized (padded) images (a forward pass of
@@ -594,89 +588,163 @@ class Bitcoding(object):
                 self._rgb_streams = (torch.cuda.Stream(), torch.cuda.Stream())
             rgb_main, rgb_side = self._rgb_streams
             rgb_main.wait_event(start)
-            group, n_img = [], 0
+            # groups of (nearly) EQUAL pixel counts below the budget: [measured, profiles/r06_set_decode_group_budget.log, 500 images = 312 MPix]
+            # groups of 48 / 96 / 160 MPix: 69 / 95 / 32 MPix/s (peak 55 / 96 / 157 GB: two consecutive groups' buffers then no longer fit the
+            # allocator's caches and every phase pays hipFree + hipMalloc)
+            pix = []
+            for files in batches:
+                _, H, W = parse_containers(files[:1]).scales[-1]
+                pix.append(len(files) * H * W)
+            n_groups = max(1, -(-sum(pix) // self.RAGGED_GROUP_PIXELS))
+            target = sum(pix) / float(n_groups)
+            group, n_img, n_pix = [], 0, 0
             for i, files in enumerate(batches):
                 group.append((i, files))
                 n_img += len(files)
-                if n_img >= self.RAGGED_GROUP or i + 1 == len(batches):
+                n_pix += pix[i]
+                if n_img >= self.RAGGED_GROUP or n_pix >= target or i + 1 == len(batches):
                     self._decode_group_ragged(group, lane_streams, rgb_main, rgb_side, out_dtype, finish)
-                    group, n_img = [], 0
+                    group, n_img, n_pix = [], 0, 0
             done.append(rgb_main.record_event())
         for ev in done:
             outer.wait_event(ev)
         return result
 
     def _decode_group_ragged(self, group, lane_streams, rgb_main, rgb_side, out_dtype, finish):
-        """One group of decode_many's ragged form: the entries' coarse scales and P of the RGB scale on the lanes, then ALL their RGB scales
-        as one ragged batch on (rgb_main, rgb_side)."""
-        n = len(lane_streams)
-        sizes = []
-        for _, files in group:                       # (H, W) of the padded image from the file's own header: the last record's shape
-            _, H, W = parse_containers(files[:1]).scales[-1]
-            sizes.append((len(files), H, W))
-        Kp = 4 * 3 * self.blueprint.net.config_ms.prob.K
-        hws = [H * W for B, H, W in sizes for _ in range(B)]
-        total = sum(hws)
-        pixbase, p = [], 0
-        for B, H, W in sizes:
-            pixbase.append(p)
-            p += B * H * W
-        with torch.cuda.stream(rgb_main):
-            P_rag = torch.empty(total * Kp, dtype=torch.float32, device='cuda')
-            sym_rag = torch.zeros(3 * total, dtype=torch.int16, device='cuda')
-            alloc_done = rgb_main.record_event()
-        deferred, small = [], []
-        for g, (i, files) in enumerate(group):
-            main, side = lane_streams[i % n]
-            main.wait_event(alloc_done)
-            P_rag.record_stream(main)
-            with torch.cuda.stream(main):
-                self._lane_side = side
-                try:
-                    d = self.decode_batch(files, out_dtype, defer_rgb=lambda B, H, W, kp, g=g: P_rag[pixbase[g] * Kp:(pixbase[g] + B * H * W) * Kp].view(B, H, W, kp))
-                finally:
-                    self._lane_side = None
-                if not isinstance(d, _DeferredRGB):      # (a model without an RGB scale 0 cannot occur; kept for safety)
-                    finish(i, d[0], d[1], main)
-                    continue
-                assert (d.B, d.H, d.W) == sizes[g], ((d.B, d.H, d.W), sizes[g])
-                deferred.append((g, i, d))
-                rgb_main.wait_event(main.record_event())
-        if not deferred:
-            return
+        """One group of decode_many's ragged form, in PHASES over all its entries (batches of different shapes):
+            lanes:   upload, the coarsest scale (uniform prior), P of the next scale (get_P per shape)      -- small launches, a lane per entry
+            ragged:  that scale's symbols of ALL images in lock step (bottleneck scale: one table launch + one decoder launch for every
+                     image and channel; RGB scale: the chunk pipeline of l3c_decode_rgb_ragged), on (rgb_main, rgb_side)
+            lanes:   P of the next finer scale ...                                                          -- and so on down to scale 0
+        An image's serial chains -- 12 ms at scale 1, 60-70 ms at scale 0 for 768x512 -- are thereby paid once per GROUP instead of once
+        per image; what is left per image are the decoder-side convolutions of its shape."""
         import numpy as np
-        K = deferred[0][2].K
-        # one stream table for the whole group: CHANNEL-major over all images; every batch keeps its own stream buffer, addressed from the lowest one
-        base_t = min((d.streams.buf for _, _, d in deferred), key=lambda t: t.data_ptr())
-        Btot = len(hws)
-        offs = np.zeros((3, Btot), dtype=np.int64)
-        lens = np.zeros((3, Btot), dtype=np.int32)
-        b0 = 0
-        for g, i, d in deferred:
-            o, l = d.streams.scale_host(d.k)                              # (3 * B,) channel-major within the batch
-            delta = d.streams.buf.data_ptr() - base_t.data_ptr()
-            offs[:, b0:b0 + d.B] = o.reshape(3, d.B) + delta
-            lens[:, b0:b0 + d.B] = l.reshape(3, d.B)
-            b0 += d.B
-        min_hw = min(hws)
-        mode = {'never': 0, 'auto': 1, 'always': 2}[self.rgb_window]
-        probe = self.RGB_PROBE if (self.rgb_window == 'auto' and min_hw >= 16 * self.RGB_PROBE) else 0
-        n_regular = max(1, min(self.RGB_CHUNKS, (min_hw - 2 * probe) // 4096))
-        pix0, npix = ops.ragged_rgb_plan(hws, n_regular, probe)
-        overlap = Btot >= 16 if self.decode_overlap is None else bool(self.decode_overlap)
+        net = self.blueprint.net
+        rgb_net = bool(net.config_ms.rgb_bicubic_baseline)
+        K = net.config_ms.prob.K
+        n = len(lane_streams)
+        st = []
+        for i, files in group:
+            parsed = parse_containers(files)
+            n_pred = len(parsed.scales) - 1
+            if n_pred < net.scales or (n_pred != net.scales and not (rgb_net and net.scales == 1)):
+                raise ValueError('invalid file: {} scale records, the model codes {}'.format(n_pred + 1, net.scales + 1))
+            st.append({'i': i, 'files': files, 'parsed': parsed, 'B': len(files), 'lane': lane_streams[i % n], 'F': None, 'n_pred': n_pred})
+        if len({e['n_pred'] for e in st}) != 1:
+            raise ValueError('decode_many: the files of a set must come from one model (different numbers of scale records)')
+        n_pred = st[0]['n_pred']
+        plan = list(self.iter_scale_dmll(n_pred))            # record k -> (scale, dmll, uniform), coarse -> fine
+        if getattr(self, '_alloc_stream', None) is None:
+            self._alloc_stream = torch.cuda.Stream()
+        mains = [m for m, _ in lane_streams]
+
+        def ragged_buffers(n_floats, n_sym):
+            # from a stream that runs nothing but the zero fill: allocated under rgb_main they would be ordered behind the previous group's whole
+            # last phase (the allocator reuses a stream's blocks in stream order) and every lane of this group would wait for it
+            with torch.cuda.stream(self._alloc_stream):
+                P_rag = torch.empty(n_floats, dtype=torch.float32, device='cuda')
+                sym_rag = torch.zeros(n_sym, dtype=torch.int16, device='cuda')
+                ev = self._alloc_stream.record_event()
+            for t in (P_rag, sym_rag):
+                for s_ in mains + [rgb_main, rgb_side]:
+                    t.record_stream(s_)
+            return P_rag, sym_rag, ev
+
+        # ---- the coarsest scale: uniform prior, one launch per entry on its lane
+        scale, dmll, uniform = plan[0]
+        assert uniform
+        for e in st:
+            C, H, W = e['parsed'].scales[0]
+            if C != net.config_ms.q.C or H < 1 or W < 1:
+                raise ValueError('invalid file: coarsest scale header (C={}, H={}, W={})'.format(C, H, W))
+            if int(e['parsed'].nbytes[0].max()) > 2 * H * W + 64:
+                raise ValueError('invalid file: coarsest scale payload longer than {} symbols can be'.format(H * W))
+            main, _ = e['lane']
+            with torch.cuda.stream(main):
+                e['streams'] = _upload_streams(e['files'], e['parsed'])
+                buf, offs, lens = e['streams'].scale(0)
+                e['sym'] = ops.ac_decode(self._uniform_row(dmll.L), buf, offs, lens, e['B'] * C, H * W, True, broadcast_row=True).reshape(e['B'], C, H, W)
+                e['hw'] = (H, W)
+        prev = dmll
+        # ---- every predicted scale, coarse -> fine
+        keep = []
+        for k in range(1, n_pred + 1):
+            scale, dmll, _ = plan[k]
+            n_params = 4 if dmll.rgb_scale else 3
+            Cs = 3 if dmll.rgb_scale else net.config_ms.q.C
+            Kp, Lp = n_params * Cs * K, dmll.L + 1
+            hws, pixbase, p = [], [], 0
+            for e in st:
+                C, H, W = e['parsed'].scales[k]
+                if (C, H, W) != (Cs, 2 * e['hw'][0], 2 * e['hw'][1]):
+                    raise ValueError('invalid file: scale {} header (C, H, W) = {} but the network predicts {}'.format(
+                        scale, (C, H, W), (Cs, 2 * e['hw'][0], 2 * e['hw'][1])))
+                pixbase.append(p)
+                p += e['B'] * H * W
+                hws += [H * W] * e['B']
+                e['hw'] = (H, W)
+            total, Btot = p, len(hws)
+            P_rag, sym_rag, alloc_ev = ragged_buffers(total * Kp, Cs * total)
+            rgb_main.wait_event(alloc_ev)
+            for g, e in enumerate(st):
+                main, side = e['lane']
+                main.wait_event(alloc_ev)
+                with torch.cuda.stream(main):
+                    bn = ops.sym_to_bn(e['sym'], prev.bin_width, prev.x_min)
+                    if rgb_net:                                  # BicubicDownsamplingEnc: the decoder is fed value - mean (net.py:72-80)
+                        bn = bn - _rgb_mean_tensor(bn.device)
+                    self._lane_side = side
+                    try:
+                        P, e['F'] = net.get_P(scale, bn, e['F'], n_scales_total=n_pred)
+                    finally:
+                        self._lane_side = None
+                    P = ops.as_pixel_major(P)
+                    H, W = e['hw']
+                    if tuple(P.shape) != (e['B'], H, W, Kp):
+                        raise ValueError('invalid file: the network predicts {} at scale {}, the file says {}'.format(tuple(P.shape), scale, (e['B'], H, W, Kp)))
+                    P_rag[pixbase[g] * Kp:(pixbase[g] + e['B'] * H * W) * Kp].view(e['B'], H, W, Kp).copy_(P)
+                    rgb_main.wait_event(main.record_event())
+            # one stream table for the whole group: CHANNEL-major over all images; every entry keeps its own stream buffer, addressed from the lowest one
+            base_t = min((e['streams'].buf for e in st), key=lambda t: t.data_ptr())
+            offs = np.zeros((Cs, Btot), dtype=np.int64)
+            lens = np.zeros((Cs, Btot), dtype=np.int32)
+            b0 = 0
+            for e in st:
+                o, l = e['streams'].scale_host(k)                             # (Cs * B,) channel-major within the entry
+                offs[:, b0:b0 + e['B']] = o.reshape(Cs, e['B']) + (e['streams'].buf.data_ptr() - base_t.data_ptr())
+                lens[:, b0:b0 + e['B']] = l.reshape(Cs, e['B'])
+                b0 += e['B']
+            targets = self._targets(dmll)
+            with torch.cuda.stream(rgb_main):
+                for e in st:
+                    e['streams'].buf.record_stream(rgb_main)
+                    e['streams'].buf.record_stream(rgb_side)
+                offs_d = ops.upload_small(offs.reshape(-1))
+                lens_d = ops.upload_small(lens.reshape(-1))
+                if dmll.rgb_scale:
+                    min_hw = min(hws)
+                    mode = {'never': 0, 'auto': 1, 'always': 2}[self.rgb_window]
+                    probe = self.RGB_PROBE if (self.rgb_window == 'auto' and min_hw >= 16 * self.RGB_PROBE) else 0
+                    n_regular = max(1, min(self.RGB_CHUNKS, (min_hw - 2 * probe) // 4096))
+                    pix0, npix = ops.ragged_rgb_plan(hws, n_regular, probe)
+                    overlap = Btot >= 16 if self.decode_overlap is None else bool(self.decode_overlap)
+                    keep.append(ops.decode_rgb_ragged(P_rag, targets, sym_rag, base_t, offs_d, lens_d, hws, pix0, npix, K,
+                                                      2 if overlap else 1, mode, rgb_side if overlap else None))
+                else:
+                    keep.append(ops.decode_z_ragged(P_rag, targets, sym_rag, base_t, offs_d, lens_d, hws, Cs, K))
+                done = rgb_main.record_event()
+            for g, e in enumerate(st):
+                H, W = e['hw']
+                a = Cs * pixbase[g]
+                e['sym'] = sym_rag[a:a + Cs * e['B'] * H * W].view(e['B'], Cs, H, W)
+                e['lane'][0].wait_event(done)
+            keep.append((sym_rag, offs_d, lens_d))
+            del P_rag          # (its block goes back to the allocator as soon as the streams that touched it have passed this point: a group's three P buffers never pile up)
+            prev = dmll
         with torch.cuda.stream(rgb_main):
-            for _, _, d in deferred:
-                d.streams.buf.record_stream(rgb_main)
-                d.streams.buf.record_stream(rgb_side)
-            offs_d = ops.upload_small(offs.reshape(-1))
-            lens_d = ops.upload_small(lens.reshape(-1))
-            keep = ops.decode_rgb_ragged(P_rag, deferred[0][2].targets, sym_rag, base_t, offs_d, lens_d, hws, pix0, npix, K,
-                                         2 if overlap else 1, mode, rgb_side if overlap else None)
-            for g, i, d in deferred:
-                a = 3 * pixbase[g]
-                pixels = sym_rag[a:a + 3 * d.B * d.H * d.W].view(d.B, 3, d.H, d.W).to(out_dtype)
-                finish(i, pixels, d.padding, rgb_main)
-            del keep
+            for e in st:
+                finish(e['i'], e['sym'].to(out_dtype), e['parsed'].padding, rgb_main)
+        del keep
 
     def _decode_z_scale(self, P, targets, streams, B, C, K, H, W):
         """A bottleneck scale: its C channels are independent given P, so ONE grouped table launch (fused, straight from P) and one
@@ -931,13 +999,6 @@ class _H2DRing(object):
 
 _UPLOAD_RING = _H2DRing(6)
 _UPLOAD_STREAM = [None]      # the files of a batch cross PCIe on a stream of their own: a lane's upload never queues behind that lane's previous batch
-
-
-class _DeferredRGB(object):
-    """A batch whose decode has stopped before the RGB scale (Bitcoding.decode_batch(defer_rgb=...)): P of that scale, its streams."""
-
-    def __init__(self, P, targets, streams, k, B, H, W, K, padding):
-        self.P, self.targets, self.streams, self.k, self.B, self.H, self.W, self.K, self.padding = P, targets, streams, k, B, H, W, K, padding
 
 
 class _DeviceStreams(object):

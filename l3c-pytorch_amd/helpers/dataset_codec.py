@@ -225,7 +225,7 @@ def decode_set(bc, files, order, max_batch=16, marks=None, lanes=None, chain_cus
 
     n_lanes = bc.N_DECODE_LANES if lanes is None else int(lanes)
     if n_pinned is None:
-        n_pinned = max(n_lanes, bc.RAGGED_GROUP) + 2          # a finished batch must never wait for a free D2H buffer (a ragged group finishes all its batches at once)
+        n_pinned = max(n_lanes, min(bc.RAGGED_GROUP, len(order))) + 2     # a finished batch must never wait for a free D2H buffer (a ragged group finishes all its batches at once)
     chunks, padded = plan_decode_set(files, order, max_batch)
     by_size = sorted(range(len(chunks)), key=lambda k: -len(chunks[k]) * padded[k][0] * padded[k][1])
     mark('plan (host)')

@@ -409,7 +409,7 @@ def decode_rgb(P_nhwc, targets, sym, buf, offs, lens, bounds, K, lag, window_mod
     return ws, stats
 
 
-_PINNED_SCRATCH = {'bufs': [None] * 4, 'events': [None] * 4, 'turn': 0}
+_PINNED_SCRATCH = {'bufs': [None] * 16, 'events': [None] * 16, 'turn': 0}
 
 
 def upload_small(array):
@@ -423,7 +423,7 @@ def upload_small(array):
         r['events'][k].synchronize()
     n = a.nbytes
     if r['bufs'][k] is None or r['bufs'][k].numel() < n:
-        r['bufs'][k] = torch.empty(max(n, 1 << 20), dtype=torch.uint8, pin_memory=True)
+        r['bufs'][k] = torch.empty(max(n, 1 << 18), dtype=torch.uint8, pin_memory=True)
     r['bufs'][k].numpy()[:n] = a.view(np.uint8).reshape(-1)
     dev = r['bufs'][k][:n].cuda(non_blocking=True)
     r['events'][k] = torch.cuda.Event()
@@ -446,7 +446,7 @@ def ragged_rgb_plan(hws, n_regular, probe):
             pix0[0, b], npix[0, b], pix0[1, b], npix[1, b] = 0, probe, probe, probe
             start, j = 2 * probe, 2
         step = (hw - start) // n_regular // 64 * 64
-        assert step >= 64, 'image too small for {} chunks'.format(n_regular)
+        assert n_regular == 1 or step >= 64, 'image too small for {} chunks'.format(n_regular)
         for k in range(n_regular):
             pix0[j + k, b] = start + k * step
             npix[j + k, b] = step if k + 1 < n_regular else hw - start - k * step
@@ -481,6 +481,42 @@ def decode_rgb_ragged(P_ragged, targets, sym_ragged, buf, offs, lens, hws, pix0,
             t.record_stream(side_stream)
     call('l3c_decode_rgb_ragged', ctypes.byref(desc), main.cuda_stream, side_stream.cuda_stream if lag == 2 else None)
     return ws, tables
+
+
+def decode_z_ragged(P_ragged, targets, sym_ragged, buf, offs, lens, hws, C, K):
+    """A bottleneck scale of B images of DIFFERENT sizes: its C channels are independent given P, so ONE ragged table launch
+    (l3c_dmll_cdf_table_ragged, C parts) and ONE ragged decoder launch (l3c_ac_decode_chunks with the r_* fields) decode every image and
+    channel side by side.  P_ragged (sum HW, 3 C K) fp32; sym_ragged int16 (C * sum HW,): image b's C planes from element C * pixbase[b];
+    streams CHANNEL-major in (buf, offs (C B,), lens (C B,)).  -> tensors to keep alive until the stream is done."""
+    import ctypes
+    import numpy as np
+    B = len(hws)
+    assert C <= 8
+    hw = np.asarray(hws, dtype=np.int64)
+    pixbase = np.concatenate([[0], np.cumsum(hw)[:-1]]).astype(np.int64)
+    Lp = targets.shape[0]
+    table_off = pixbase * (Lp * 2)                    # every image's whole plane is one range: npix = hw, pix0 = 0
+    tables = upload_small(np.concatenate([pixbase, hw, np.zeros(B, dtype=np.int64), hw, table_off]).astype(np.int64))
+    base = tables.data_ptr()
+    total = int(hw.sum())
+    flag = torch.zeros(1, dtype=torch.int32, device=P_ragged.device)
+    tabs = [torch.empty(total * Lp, dtype=torch.int16, device=P_ragged.device) for _ in range(C)]
+    batch = _lib.RaggedBatch(B, int(hw.max()), base, base + 8 * B)
+    tparts = (_lib.TablePart * C)()
+    rparts = (_lib.RaggedPart * C)()
+    dparts = (_lib.AcDecodePart * C)()
+    for c in range(C):
+        tparts[c] = _lib.TablePart(c, 0, int(hw.max()), ptr(tabs[c]), ptr(flag, torch.int32), None)
+        rparts[c] = _lib.RaggedPart(base + 16 * B, base + 24 * B, base + 32 * B)
+        d = _lib.AcDecodePart(ptr(tabs[c]), Lp, ptr(buf, torch.uint8), ptr(offs[c * B:(c + 1) * B], torch.int64), ptr(lens[c * B:(c + 1) * B], torch.int32),
+                              B, int(hw.max()), ptr(flag, torch.int32), None, None, 1, ptr(sym_ragged, torch.int16), 0, 0)
+        d.r_npix, d.r_table_off, d.r_pixbase, d.r_hw, d.r_pix0 = base + 24 * B, base + 32 * B, base, base + 8 * B, base + 16 * B
+        d.r_C, d.r_c, d.r_table_bytes = C, c, total * Lp * 2
+        dparts[c] = d
+    call('l3c_dmll_cdf_table_ragged', ptr(P_ragged, torch.float32), None, ptr(targets, torch.float32), ctypes.byref(batch), C, K, 0, Lp,
+         tparts, rparts, C, stream())
+    call('l3c_ac_decode_chunks', dparts, C, stream())
+    return tabs, tables, flag
 
 
 def container_read(files_dev, src_off, dst_off, nbytes, max_nbytes, dst):

@@ -198,3 +198,25 @@ def test_decode_set_gives_back_every_image_of_an_encoded_set(l3c_checkpoint):
     res = bc.decode_many([[files[0]], [files[4], files[13]], [files[2]]], lanes=2)
     assert [tuple(r[0].shape) for r in res] == [(1, 3, 200, 264), (2, 3, 72, 88), (1, 3, 136, 264)] and all(r[0].dtype == torch.int64 for r in res)
     assert torch.equal(res[1][0][1].cpu(), imgs[13].long())
+
+
+def test_decode_set_of_rgb_shared_files_with_recursion():
+    """The set decoder's ragged phases on the OTHER model family: RGB Shared with auto_recurse 3 -- five scale records, every predicted scale an
+    RGB scale (three lambda-coupled chains, the chunk pipeline of l3c_decode_rgb_ragged at every scale, tiny coarse scales included)."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding, count_scale_records
+    from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
+    from l3c_pytorch_amd.helpers import config_parser, dataset_codec, synthetic
+    cfg = config_parser.parse_builtin('ms', 'cr_rgb_shared')
+    bp = MultiscaleBlueprint(cfg)
+    bp.net.load_state_dict(synthetic.make_state_dict(cfg, 0, calibrated=True), strict=True)
+    bp.set_eval()
+    bc = Bitcoding(bp, auto_recurse=3)
+    shapes = [(96, 160), (75, 100), (96, 160), (64, 80), (133, 70), (75, 100), (160, 96)]
+    imgs = {i: synthetic.make_image(h, w, 500 + i, 'natural') for i, (h, w) in enumerate(shapes)}
+    order = list(range(len(shapes)))
+    files, _, _ = dataset_codec.encode_set(bc, imgs, order, max_batch=4, fac=16)
+    assert all(count_scale_records(files[i]) == 5 for i in order)
+    for kw in (dict(), dict(lanes=1), dict(ragged=False, lanes=2)):
+        back = dataset_codec.decode_set(bc, files, order, max_batch=4, **kw)
+        for i in order:
+            assert torch.equal(back[i], imgs[i]), (kw, i)

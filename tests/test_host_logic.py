@@ -468,3 +468,22 @@ def test_balanced_cu_sets_hold_every_xcd_equally():
     import pytest
     with pytest.raises(ValueError):
         runtime.balanced_cu_sets(256, 40)
+
+
+def test_ragged_rgb_plan_tiles_every_image_in_lock_step():
+    """`ops.ragged_rgb_plan`: the chunk plan of the set decoder's ragged RGB pipeline (l3c_decode_rgb_ragged validates the same on the C side):
+    every image the same NUMBER of chunks, its chunks tile [0, HW) in order, none empty, every boundary but the image's end on a multiple of 64."""
+    import numpy as np
+    from l3c_pytorch_amd import ops
+    hws = [512 * 768, 768 * 512, 584 * 880, 1024 * 1368, 131072 + 64, 400 * 400]
+    for n_regular, probe in ((32, 1024), (32, 0), (7, 1024), (1, 0)):
+        pix0, npix = ops.ragged_rgb_plan(hws, n_regular, probe)
+        assert pix0.shape == npix.shape == (n_regular + (2 if probe else 0), len(hws))
+        for b, hw in enumerate(hws):
+            assert (npix[:, b] > 0).all() and pix0[0, b] == 0
+            assert (pix0[1:, b] == np.cumsum(npix[:-1, b])).all() and pix0[-1, b] + npix[-1, b] == hw
+            assert (pix0[:, b] % 64 == 0).all()
+            if probe:
+                assert npix[0, b] == npix[1, b] == probe
+    pix0, npix = ops.ragged_rgb_plan([6, 24, 96], 1, 0)          # the coarsest scales of an RGB Shared file: one chunk each
+    assert npix.tolist() == [[6, 24, 96]]
