@@ -525,7 +525,7 @@ class Bitcoding(object):
         return self._lane_streams
 
     RAGGED_GROUP = 512               # decode_many: at most this many images are decoded together as one ragged group ...
-    RAGGED_GROUP_PIXELS = 96 << 20   # ... and at most this many pixels (P of the RGB scale is 480 bytes per pixel: 48 GB; its tables 6 GB)
+    RAGGED_GROUP_PIXELS = 128 << 20  # ... and at most this many pixels (P of the RGB scale is 480 bytes per pixel: 64 GB; its tables 8 GB)
 
     def decode_many(self, batches, on_batch=None, lanes=None, chain_cus=0, out_dtype=torch.int64, ragged=None):
         """batches: list of lists of `.l3c` byte strings; the files of ONE entry are equally sized (padded) images (a forward pass of

@@ -89,6 +89,8 @@ timeout 600 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_REQ_sum 
 [ -d $E/pmc ] && python tools/pmc_tcc.py $E/pmc_tcc $E/pmc > $E/tcc_per_variant.json 2>> $E/pmc_tcc.err
 rm -rf $E/pmc_tcc
 timeout 900 python tools/decode_concurrency_probe.py 2>&1 | grep -v amdgpu.ids > $E/decode_concurrency_probe.log
+# the whole GPU suite on the final code
+timeout 3000 python -m pytest tests -m gpu -q > $E/pytest_gpu.log 2>&1; tail -3 $E/pytest_gpu.log
 # keep the merge-back small: the raw traces stay on the box
 rm -rf $E/stats $E/pmc $E/pmcd $E/dtrace $E/pmc_tcc
 ls -la $E
