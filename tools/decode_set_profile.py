@@ -30,6 +30,8 @@ for rep in range(3):
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     print('decode_set of {} images: returned after {:.3f} s ({:.1f} MPix/s); plan {:.3f} s'.format(N, t1 - t0, pix / (t1 - t0), marks['plan (host)'] - t0), flush=True)
+torch.cuda.synchronize()
+time.sleep(0.4)      # a gap in the kernel trace: tools/trace_busy.py analyses the LAST burst
 pr = cProfile.Profile()
 pr.enable()
 back = dataset_codec.decode_set(bc, files, order, max_batch=16)
