@@ -220,3 +220,97 @@ def test_decode_set_of_rgb_shared_files_with_recursion():
         back = dataset_codec.decode_set(bc, files, order, max_batch=4, **kw)
         for i in order:
             assert torch.equal(back[i], imgs[i]), (kw, i)
+
+
+def test_decode_set_in_many_small_groups_with_tiny_and_large_images_side_by_side(l3c_checkpoint):
+    """The ragged phases at their corners: an 8x8 image (64 symbols a channel: ONE chunk for every image of its group, no probe chunks) beside a
+    512x768 one, sizes that need padding on both axes, and group limits small enough that the 14 images go through SEVERAL groups (the buffers
+    of consecutive groups, the lanes' waits between groups) -- every image compared with its input; then the same set in one group."""
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.helpers import dataset_codec, synthetic
+    bp, sd = _blueprint(l3c_checkpoint, True)
+    bc = Bitcoding(bp)
+    shapes = [(8, 8), (512, 768), (9, 17), (64, 96), (8, 8), (200, 264), (16, 8), (133, 261), (8, 8), (64, 96), (24, 40), (512, 768), (72, 88), (9, 17)]
+    imgs = {i: synthetic.make_image(h, w, 700 + i, 'natural') for i, (h, w) in enumerate(shapes)}
+    order = list(range(len(shapes)))
+    files, _, _ = dataset_codec.encode_set(bc, imgs, order, max_batch=2)
+    for group, pixels in ((3, 1 << 40), (512, 100 * 1000), (512, 128 << 20)):
+        bc.RAGGED_GROUP, bc.RAGGED_GROUP_PIXELS = group, pixels            # (instance attributes: the class constants stay)
+        for kw in (dict(max_batch=2), dict(max_batch=1, lanes=3)):
+            back = dataset_codec.decode_set(bc, files, order, **kw)
+            for i in order:
+                assert torch.equal(back[i], imgs[i]), (group, pixels, kw, i)
+
+
+def test_set_decoder_rejects_files_that_do_not_fit_the_model_and_survives_them(l3c_checkpoint):
+    """The headers of a `.l3c` file are untrusted input (the reference fails with a shape error, bitcoding.py:248-266): a wrong H in a scale
+    record, a record missing, a truncated file, a file of the other model family -> ValueError from `decode_batch` AND from the ragged set
+    path (before any kernel indexes P with them); payload bytes that are noise decode to SOME pixels of the right shape, like the reference's
+    decoder does; and the same Bitcoding object decodes a good set afterwards (streams, rings and events are left usable)."""
+    import struct
+    import numpy as np
+    from l3c_pytorch_amd.bitcoding.bitcoding import Bitcoding
+    from l3c_pytorch_amd.blueprints.multiscale_blueprint import MultiscaleBlueprint
+    from l3c_pytorch_amd.helpers import config_parser, dataset_codec, synthetic
+    bp, sd = _blueprint(l3c_checkpoint, True)
+    bc = Bitcoding(bp)
+    shapes = [(64, 96), (72, 88), (64, 96), (40, 56)]
+    imgs = {i: synthetic.make_image(h, w, 800 + i, 'natural') for i, (h, w) in enumerate(shapes)}
+    order = list(range(len(shapes)))
+    files, _, _ = dataset_codec.encode_set(bc, imgs, order, max_batch=2)
+    good = files[1]
+
+    def walk(f):
+        """-> [(offset of the record header, C, H, W, [(payload offset, nbytes)])]"""
+        p, recs = 8, []
+        while p < len(f):
+            C, H, W = struct.unpack_from('<BHH', f, p)
+            q, chans = p + 5, []
+            for _ in range(C):
+                n, = struct.unpack_from('<I', f, q)
+                chans.append((q + 4, n))
+                q += 4 + n
+            recs.append((p, C, H, W, chans))
+            p = q + 4
+        return recs
+
+    recs = walk(good)
+    assert len(recs) == 4 and recs[-1][1:4] == (3, 72, 88)
+    bad = {}
+    b = bytearray(good)
+    struct.pack_into('<H', b, recs[-1][0] + 1, 80)                       # the RGB record says H = 80
+    bad['wrong H at the RGB scale'] = bytes(b)
+    b = bytearray(good)
+    struct.pack_into('<H', b, recs[1][0] + 3, recs[1][3] * 2)             # a bottleneck record says twice the width
+    bad['wrong W at a bottleneck scale'] = bytes(b)
+    b = bytearray(good)
+    b[recs[0][0]] = 7                                                     # the coarsest record says 7 channels: the framing no longer parses
+    bad['wrong C at the coarsest scale'] = bytes(b)
+    bad['truncated'] = good[:len(good) - 37]
+    bad['a record missing'] = good[:8] + good[recs[1][0]:]
+    cfg_rgb = config_parser.parse_builtin('ms', 'cr_rgb_shared')
+    bp_rgb = MultiscaleBlueprint(cfg_rgb)
+    bp_rgb.net.load_state_dict(synthetic.make_state_dict(cfg_rgb, 0, calibrated=True), strict=True)
+    bp_rgb.set_eval()
+    other, _, _ = dataset_codec.encode_set(Bitcoding(bp_rgb, auto_recurse=3), {0: synthetic.make_image(96, 160, 1, 'natural')}, [0], max_batch=1, fac=16)
+    bad['a file of the RGB Shared model (five records)'] = other[0]
+    for name, f in bad.items():
+        with pytest.raises(ValueError):
+            bc.decode_batch([f])
+        with pytest.raises(ValueError):
+            dataset_codec.decode_set(bc, {**files, 1: f}, order, max_batch=2)
+        torch.cuda.synchronize()
+    # noise in the payloads, framing intact: decodes to pixels of the right shape (whatever they are), no error, no hang
+    rng = np.random.RandomState(5)
+    b = bytearray(good)
+    for _, _, _, _, chans in recs:
+        for off, n in chans:
+            b[off:off + n] = rng.randint(0, 256, size=n).astype(np.uint8).tobytes()
+    back = dataset_codec.decode_set(bc, {**files, 1: bytes(b)}, order, max_batch=2)
+    assert tuple(back[1].shape) == (3, 72, 88) and back[1].dtype == torch.uint8
+    for i in (0, 2, 3):
+        assert torch.equal(back[i], imgs[i]), i                            # the files beside it are untouched by it
+    # and the object is as good as new
+    back = dataset_codec.decode_set(bc, files, order, max_batch=2)
+    for i in order:
+        assert torch.equal(back[i], imgs[i]), i
