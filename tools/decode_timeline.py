@@ -44,6 +44,13 @@ def main():
     u = union([(a, b) for a, b, _ in rows])
     gaps = sorted(((c - b, b - t0) for (a, b), (c, d) in zip(u, u[1:])), reverse=True)[:8]
     print('largest idle gaps (ms, at ms):', [(round(g * ms, 2), round(at * ms, 1)) for g, at in gaps])
+    if len(sys.argv) > 2 and sys.argv[2] == 'around':      # what ran right before and right after the four largest gaps
+        for g, at in gaps[:4]:
+            before = sorted((r for r in rows if r[1] - t0 <= at), key=lambda r: r[1])[-4:]
+            after = sorted((r for r in rows if r[0] - t0 >= at + g), key=lambda r: r[0])[:6]
+            print('gap of {:.2f} ms at {:.1f} ms: before: {} | after: {}'.format(
+                g * ms, at * ms, ', '.join('{} (ended {:.2f} ms before)'.format(n[:40], (at - (b - t0)) * ms) for a, b, n in before),
+                ', '.join('{} (+{:.2f} ms)'.format(n[:40], (a - t0 - at - g) * ms) for a, b, n in after)))
 
 
 if __name__ == '__main__':
