@@ -44,6 +44,19 @@ def main():
     u = union([(a, b) for a, b, _ in rows])
     gaps = sorted(((c - b, b - t0) for (a, b), (c, d) in zip(u, u[1:])), reverse=True)[:8]
     print('largest idle gaps (ms, at ms):', [(round(g * ms, 2), round(at * ms, 1)) for g, at in gaps])
+    if len(sys.argv) > 2 and sys.argv[2] == 'clusters':    # when each kernel ran: its launches clustered (gaps > 30 ms split), as [start, end] x n in ms
+        for n, iv in sorted(names.items(), key=lambda kv: min(a for a, _ in kv[1])):
+            iv = sorted(iv)
+            cl, cur = [], [iv[0][0], iv[0][1], 1]
+            for a, b in iv[1:]:
+                if a - cur[1] > 30e6:
+                    cl.append(cur)
+                    cur = [a, b, 1]
+                else:
+                    cur[1] = max(cur[1], b)
+                    cur[2] += 1
+            cl.append(cur)
+            print('{:60s} {}'.format(n[:60], '  '.join('[{:.0f}, {:.0f}] x{}'.format((a - t0) * ms, (b - t0) * ms, k) for a, b, k in cl)))
     if len(sys.argv) > 2 and sys.argv[2] == 'around':      # what ran right before and right after the four largest gaps
         for g, at in gaps[:4]:
             before = sorted((r for r in rows if r[1] - t0 <= at), key=lambda r: r[1])[-4:]
