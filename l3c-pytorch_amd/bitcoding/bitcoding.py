@@ -473,10 +473,10 @@ class Bitcoding(object):
         bn_prev, F_prev, sym, prev_hw = None, None, None, None
         for k, (scale, dmll, uniform) in enumerate(self.iter_scale_dmll(n_pred)):
             C, H, W = parsed.scales[k]
-            buf, offs, lens = streams.scale(k)
             # the headers are untrusted input: a wrong C / H / W would make the table and decoder kernels index P and the symbol
             # buffers out of bounds (the reference fails with a shape error here, bitcoding.py:248-266)
             if uniform:
+                buf, offs, lens = streams.scale(k)
                 if C != net.config_ms.q.C or H < 1 or W < 1:
                     raise ValueError('invalid file: coarsest scale header (C={}, H={}, W={})'.format(C, H, W))
                 if int(parsed.nbytes[k].max()) > 2 * H * W + 64:      # > 16 bits per symbol: not a stream of this coder
@@ -492,6 +492,7 @@ class Bitcoding(object):
                     raise ValueError('invalid file: scale {} header (C, H, W) = {} but the network predicts {}'.format(
                         scale, (C, H, W), expect))
                 targets = self._targets(dmll)
+                buf, offs, lens = streams.scale(k)      # (the last record's streams are staged and uploaded HERE: behind the convolutions just enqueued)
                 if dmll.rgb_scale:
                     sym = self._decode_rgb_pipelined(P, targets, (buf, offs, lens), B, C, K, H, W)
                 else:
@@ -719,6 +720,8 @@ class Bitcoding(object):
                 for e in st:
                     e['streams'].buf.record_stream(rgb_main)
                     e['streams'].buf.record_stream(rgb_side)
+                    if k == n_pred:
+                        e['streams'].finish()       # the bulk of the files (the last record) crosses PCIe here, behind the convolutions just enqueued
                 offs_d = ops.upload_small(offs.reshape(-1))
                 lens_d = ops.upload_small(lens.reshape(-1))
                 if dmll.rgb_scale:
@@ -1002,11 +1005,19 @@ _UPLOAD_STREAM = [None]      # the files of a batch cross PCIe on a stream of th
 
 
 class _DeviceStreams(object):
-    """The entropy-coded streams of a batch of files on the device, 4-byte aligned and zero padded, all scales in one buffer."""
+    """The entropy-coded streams of a batch of files on the device, 4-byte aligned and zero padded, all scales in one buffer.
+    The streams of the LAST scale record (the finest scale: ~95 % of a file's bytes) may still be on the host: `finish()` -- called by
+    `scale(last)`, or by the set decoder before its last phase -- stages, uploads and cuts them out then, under the stream that is current."""
 
-    def __init__(self, buf, offs, lens, first, count, offs_host=None, lens_host=None):
+    def __init__(self, buf, offs, lens, first, count, offs_host=None, lens_host=None, pending=None):
         self.buf, self.offs, self.lens, self.first, self.count = buf, offs, lens, first, count
         self.offs_host, self.lens_host = offs_host, lens_host       # (numpy: the set decoder merges the tables of several batches on the host)
+        self.pending = pending
+
+    def finish(self):
+        if self.pending is not None:
+            pending, self.pending = self.pending, None
+            pending()
 
     def scale_host(self, k):
         a, n = self.first[k], self.count[k]
@@ -1015,19 +1026,45 @@ class _DeviceStreams(object):
     def scale(self, k):
         """(buffer, offsets int64, lengths int32) of scale record k: the coarsest record in image-major order (stream b * C + c, what
         the uniform-prior decoder writes as (B, C, H, W)), the others channel-major (stream c * B + b: a channel's B streams adjacent)."""
+        if k == len(self.first) - 1:
+            self.finish()
         a, n = self.first[k], self.count[k]
         return self.buf, self.offs[a:a + n], self.lens[a:a + n]
 
 
+def _upload_stream():
+    if _UPLOAD_STREAM[0] is None:
+        _UPLOAD_STREAM[0] = torch.cuda.Stream()
+    return _UPLOAD_STREAM[0]
+
+
+def _h2d(stage, k, dev_slice):
+    """One asynchronous copy of a staging buffer of the upload ring on the upload stream; the current stream waits for it."""
+    cur = torch.cuda.current_stream()
+    with torch.cuda.stream(_upload_stream()):
+        dev_slice.copy_(stage, non_blocking=True)
+        _UPLOAD_RING.sent(k)
+        copied = torch.cuda.Event()
+        copied.record(_UPLOAD_STREAM[0])
+    cur.wait_event(copied)
+
+
 def _upload_streams(files, parsed):
-    """Files -> _DeviceStreams on the current stream: ONE page-locked buffer holding the raw files and the stream table, ONE H2D copy,
-    ONE kernel (l3c_container_read).  No payload byte is touched by Python."""
+    """Files -> _DeviceStreams on the current stream: page-locked staging, asynchronous H2D copies on the upload stream, l3c_container_read cuts
+    the streams out on the device.  No payload byte is touched by Python.
+    In TWO parts: everything before a file's last scale record (a twentieth of its bytes) and the stream table now, the last record's streams
+    when they are asked for (`_DeviceStreams.finish`): the host's staging copy of the bulk (20 ms for a batch of 128) then runs while the
+    GPU is busy with the coarse scales, not before its first kernel [measured, same box: 0.366 -> see DESIGN 7.2]."""
     B = len(files)
-    sizes = [len(f) for f in files]
-    base = np.concatenate([[0], np.cumsum([(n + 3) // 4 * 4 for n in sizes])]).astype(np.int64)     # files 4-byte aligned in the buffer
+    sizes = np.asarray([len(f) for f in files], dtype=np.int64)
+    last = len(parsed.scales) - 1
+    cut = parsed.offset[last][:, 0] - 9                     # the last record's header: u8 C, u16 H, u16 W, then channel 0's u32 length
+    al = lambda n: (n + 3) // 4 * 4                         # noqa: E731 -- file pieces 4-byte aligned in the buffer
+    base_a = np.concatenate([[0], np.cumsum(al(cut))]).astype(np.int64)
+    base_b = np.concatenate([[0], np.cumsum(al(sizes - cut))]).astype(np.int64)
     src, dst_len, first, count = [], [], [], []
     for k, (C, H, W) in enumerate(parsed.scales):
-        o = parsed.offset[k] + base[:B, None]
+        o = parsed.offset[k] + (base_a[:B, None] if k < last else (base_b[:B] - cut)[:, None])     # (the last record: relative to part B's start, added below)
         n = parsed.nbytes[k]
         if k:                                        # channel-major
             o, n = o.T, n.T
@@ -1035,37 +1072,48 @@ def _upload_streams(files, parsed):
         count.append(B * C)
         src.append(o.reshape(-1))
         dst_len.append(n.reshape(-1))
-    src = np.concatenate(src)
+    S_a = first[last]
     lens = np.concatenate(dst_len)
     padded = (lens + 3) // 4 * 4 + 4
     dst = np.concatenate([[0], np.cumsum(padded)[:-1]]).astype(np.int64)
-    S = src.shape[0]
-    files_bytes = int(base[-1])
-    table_at = (files_bytes + 7) // 8 * 8
-    total = table_at + S * (8 + 8 + 4)
-    k, stage = _UPLOAD_RING.take(total)
+    S = lens.shape[0]
+    a_bytes = int(base_a[-1])
+    table_at = (a_bytes + 7) // 8 * 8
+    b_at = table_at + (S * 20 + 7) // 8 * 8
+    b_bytes = int(base_b[-1])
+    src[last] = src[last] + b_at
+    src = np.concatenate(src)
+    k, stage = _UPLOAD_RING.take(b_at)
     st = stage.numpy()
     for b, f in enumerate(files):
-        st[base[b]:base[b] + sizes[b]] = np.frombuffer(f, dtype=np.uint8)
+        st[base_a[b]:base_a[b] + cut[b]] = np.frombuffer(f, dtype=np.uint8, count=int(cut[b]))
     st[table_at:table_at + 8 * S] = src.view(np.uint8)
     st[table_at + 8 * S:table_at + 16 * S] = dst.view(np.uint8)
     st[table_at + 16 * S:table_at + 20 * S] = lens.astype(np.int32).view(np.uint8)
-    if _UPLOAD_STREAM[0] is None:
-        _UPLOAD_STREAM[0] = torch.cuda.Stream()
     cur = torch.cuda.current_stream()
-    with torch.cuda.stream(_UPLOAD_STREAM[0]):
-        dev = stage.cuda(non_blocking=True)
-        _UPLOAD_RING.sent(k)
-        copied = torch.cuda.Event()
-        copied.record(_UPLOAD_STREAM[0])
-    cur.wait_event(copied)
+    with torch.cuda.stream(_upload_stream()):       # (the upload stream's pool: the copies that fill it are ordered behind that block's previous use)
+        dev = torch.empty(b_at + b_bytes, dtype=torch.uint8, device='cuda')
     dev.record_stream(cur)
+    _h2d(stage, k, dev[:b_at])
     src_d = dev[table_at:table_at + 8 * S].view(torch.int64)
     dst_d = dev[table_at + 8 * S:table_at + 16 * S].view(torch.int64)
     len_d = dev[table_at + 16 * S:table_at + 20 * S].view(torch.int32)
     out = torch.empty(int(padded.sum()), dtype=torch.uint8, device='cuda')
-    ops.container_read(dev, src_d, dst_d, len_d, int(lens.max()), out)
-    return _DeviceStreams(out, dst_d, len_d, first, count, dst, lens)
+    ops.container_read(dev, src_d[:S_a], dst_d[:S_a], len_d[:S_a], int(lens[:S_a].max()), out)
+
+    def finish():
+        k2, stage2 = _UPLOAD_RING.take(b_bytes)
+        st2 = stage2.numpy()
+        for b, f in enumerate(files):
+            st2[base_b[b]:base_b[b] + sizes[b] - cut[b]] = np.frombuffer(f, dtype=np.uint8, offset=int(cut[b]))
+        now = torch.cuda.current_stream()
+        if now != cur:
+            dev.record_stream(now)
+            out.record_stream(now)
+        _h2d(stage2, k2, dev[b_at:])
+        ops.container_read(dev, src_d[S_a:], dst_d[S_a:], len_d[S_a:], int(lens[S_a:].max()), out)
+
+    return _DeviceStreams(out, dst_d, len_d, first, count, dst, lens, finish)
 
 
 def count_scale_records(data):
